@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (`/root/reference`,
+imported in this container) on the build's seeded synthetic checkpoint + synthetic inputs.
+
+Run (build container only; /root/reference does not exist on the GPU box):
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, prints oracle-vs-reference diffs
+
+Recipe:
+  1. put tests/golden/ref_shims on sys.path (torchlibrosa / torchaudio / importlib_resources are not
+     installed here; see ref_shims/README.md — parity unpinned at those boundaries);
+  2. monkeypatch AutoModelForCausalLM.from_pretrained (reference decoder.py:25, a network call) to build
+     a random-init LlamaForCausalLM with the SmolLM2-135M hyper-parameters of
+     mellow_amd/config/lm_smollm2_135m.yaml;
+  3. construct `Mellow(...)` exactly as reference wrapper.py:66-73, `load_state_dict(strict=True)` the
+     synthetic checkpoint (mellow_amd.synth.make_state_dict), `.eval()`;
+  4. drive `Mellow.generate_prefix_inference` (mellow.py:100-108) and the unmodified
+     `MellowWrapper._generate_batch` (wrapper.py:197-256) on an instance made with `__new__`
+     (skipping the hub downloads of wrapper.py:41-42,84) with a stub tokenizer.
+
+The vectors are DATA (inputs are regenerated from seeds; outputs are stored, sub-sampled where large).
+No reference source text is stored.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "ref_shims"))
+sys.path.insert(0, REF)
+
+from mellow_amd import spec, synth  # noqa: E402
+from oracle import mellow_oracle as O  # noqa: E402
+
+SEED = 0
+N_STEPS = 12
+SUB_VOCAB = np.arange(0, 49152, 96)  # 512 logits kept per step
+
+
+def build_reference(sd):
+    import transformers
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    lmc = spec.LMConfig.load()
+
+    def fake_from_pretrained(name, *a, **k):
+        cfg = LlamaConfig(vocab_size=lmc.vocab_size, hidden_size=lmc.hidden_size,
+                          intermediate_size=lmc.intermediate_size, num_hidden_layers=lmc.num_hidden_layers,
+                          num_attention_heads=lmc.num_attention_heads, num_key_value_heads=lmc.num_key_value_heads,
+                          max_position_embeddings=lmc.max_position_embeddings, rms_norm_eps=lmc.rms_norm_eps,
+                          rope_theta=lmc.rope_theta, tie_word_embeddings=lmc.tie_word_embeddings,
+                          hidden_act="silu", attention_bias=False, mlp_bias=False,
+                          bos_token_id=lmc.bos_token_id, eos_token_id=lmc.eos_token_id)
+        return LlamaForCausalLM(cfg)
+
+    transformers.AutoModelForCausalLM.from_pretrained = staticmethod(fake_from_pretrained)
+    import mellow.model.decoder as ref_decoder
+    ref_decoder.AutoModelForCausalLM.from_pretrained = staticmethod(fake_from_pretrained)
+    from mellow.model.model import get_model_class
+    import yaml
+    with open(os.path.join(REF, "mellow", "config", "v0.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    Model = get_model_class(cfg["model"]["model_type"])
+    model = Model(audioenc_name=cfg["model"]["encoder"]["audioenc_name"], d_in=cfg["model"]["encoder"]["out_emb"],
+                  text_decoder=cfg["model"]["decoder"]["text_decoder"],
+                  prefix_length=cfg["model"]["decoder"]["prefix_length"], d_out=cfg["model"]["encoder"]["d_proj"])
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+    n_params = sum(p.numel() for p in model.parameters())
+    print(f"reference model built: {n_params} parameters, {len(model.state_dict())} state_dict entries; {missing}")
+    assert n_params == 167020951, n_params
+    return model, cfg
+
+
+class StubTokenizer:
+    def __init__(self, stop_id):
+        self.stop_id = stop_id
+
+    def encode(self, s):
+        return [self.stop_id]
+
+    def decode(self, ids):
+        # token-level stand-in: one "word" per id, stop id rendered as the stop string
+        return " ".join("<|endoftext|>" if int(i) == self.stop_id else f"t{int(i)}" for i in np.atleast_1d(ids))
+
+
+def ref_generate_tokens(model, prefix, steps, stop_id, top_p=0.8, temperature=1.0):
+    """Run the reference's own loop and capture tokens + per-step last-position logits via a hook."""
+    from mellow.wrapper import MellowWrapper
+    w = MellowWrapper.__new__(MellowWrapper)
+    w.model = model
+    w.tokenizer = StubTokenizer(stop_id)
+    logits_log = []
+    h = model.caption_decoder.lm.register_forward_hook(
+        lambda m, i, o: logits_log.append(o.logits[:, -1, :].detach().clone()))
+    try:
+        strings = w._generate_batch(embed=prefix, entry_length=steps, top_p=top_p, temperature=temperature)
+    finally:
+        h.remove()
+    toks = []
+    for s in strings:
+        toks.append([int(t[1:]) for t in s.split() if t.startswith("t")])
+    return strings, toks, logits_log
+
+
+def maxdiff(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max()), float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE)
+    ap.add_argument("--skip-long", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    t0 = time.time()
+    sd = synth.make_state_dict(SEED)
+    print(f"synthetic checkpoint: {len(sd)} entries ({time.time() - t0:.1f}s)")
+    model, cfg = build_reference(sd)
+    lmp = O.LMParams()
+
+    # ------------------------------------------------------------------ case "enc10": B=2, 10 s
+    B = 2
+    a1, a2, ids = synth.make_batch(B)
+    a1t, a2t, idst = torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids)
+    taps = {}
+    hooks = []
+    ht = model.audio_encoder.base.htsat
+
+    def tap(name):
+        def f(m, i, o):
+            if name not in taps:         # first call = audio1 pass (mellow.py:105)
+                taps[name] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+        return f
+
+    hooks.append(ht.spectrogram_extractor.register_forward_hook(tap("power")))
+    hooks.append(ht.logmel_extractor.register_forward_hook(tap("logmel")))
+    hooks.append(ht.bn0.register_forward_hook(tap("bn0_raw")))           # (B,64,1001,1) transposed view
+    hooks.append(ht.patch_embed.register_forward_hook(tap("patch")))
+    for s in range(4):
+        hooks.append(ht.layers[s].register_forward_hook(tap(f"stage{s}")))
+    hooks.append(model.audio_encoder.projection.register_forward_hook(tap("projected")))
+    with torch.no_grad():
+        prefix, od1, od2 = model.generate_prefix_inference({"audio1": a1t, "audio2": a2t, "input": {"input_ids": idst}})
+    for h in hooks:
+        h.remove()
+    print(f"reference prefix: {tuple(prefix.shape)} ({time.time() - t0:.1f}s)")
+
+    # oracle on the same inputs
+    otaps = {}
+    with torch.no_grad():
+        oprefix = O.generate_prefix_inference(sd, a1t, a2t, idst, otaps)
+    ref_logmel_bn = taps["bn0_raw"].transpose(1, 3)
+    checks = {
+        "power": (otaps["power"], taps["power"]),
+        "logmel": (otaps["logmel"], taps["logmel"]),
+        "logmel_bn": (otaps["logmel_bn"], ref_logmel_bn),
+        "patch": (otaps["patch"], taps["patch"]),
+        **{f"stage{s}": (otaps[f"stage{s}"], taps[f"stage{s}"]) for s in range(4)},
+        "latent": (otaps["latent"], od1["latent_output"]),
+        "framewise": (otaps["framewise"], od1["framewise_output"]),
+        "embedding": (otaps["embedding"], od1["embedding"]),
+        "projected": (otaps["projected"], taps["projected"]),
+        "prefix": (oprefix, prefix),
+    }
+    print("oracle vs imported reference (max abs, max abs / max|ref|):")
+    for k, (o, r) in checks.items():
+        d = maxdiff(o, r)
+        print(f"  {k:10s} {d[0]:.3e} {d[1]:.3e}   shape {tuple(r.shape)}")
+        assert d[1] < 1e-4, (k, d)
+
+    tok_idx = np.arange(0, 4096, 41)       # 100 patch tokens
+    fw = od1["framewise_output"]
+    assert torch.equal(fw[:, 0::32, :].repeat_interleave(32, dim=1), fw)   # only 32 distinct rows
+    np.savez_compressed(
+        os.path.join(args.out, "enc10.npz"),
+        seed=SEED, B=B,
+        power_sub=taps["power"][:, 0, ::50, ::8].numpy(),                  # (B,21,65)
+        logmel=taps["logmel"][:, 0].numpy().astype(np.float32),           # (B,1001,64)
+        logmel_bn_sub=ref_logmel_bn[:, 0, ::10, :].numpy(),               # (B,101,64)
+        patch_sub=taps["patch"][:, tok_idx, :].numpy(), tok_idx=tok_idx,
+        stage0_sub=taps["stage0"][:, ::11, :].numpy(),
+        stage1_sub=taps["stage1"][:, ::5, :].numpy(),
+        stage2=taps["stage2"].numpy(),
+        stage3=taps["stage3"].numpy(),
+        latent=od1["latent_output"].numpy(),
+        framewise32=fw[:, 0::32, :].numpy(),                                # (B,32,527)
+        embedding33=torch.cat((od1["embedding"][:, :1], od1["embedding"][:, 1::32]), 1).numpy(),
+        projected33=torch.cat((taps["projected"][:, :1], taps["projected"][:, 1::32]), 1).numpy(),
+        prefix=prefix.numpy(),                                              # (B,389,576)
+    )
+
+    # ------------------------------------------------------------------ case "gen": greedy tokens + logits
+    with torch.no_grad():
+        strings, toks, logits_log = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0)
+        strings2, toks2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0, top_p=0.1, temperature=0.3)
+    toks = np.asarray(toks, dtype=np.int64)
+    assert np.array_equal(toks, np.asarray(toks2)), "sampling params changed greedy result (SURVEY A16)"
+    L = torch.stack(logits_log)                                             # (steps,B,V)
+    top2 = torch.topk(L, 2, dim=-1).values
+    gaps = (top2[..., 0] - top2[..., 1]).numpy()
+    print(f"reference tokens ({time.time() - t0:.1f}s):\n{toks}\nmin top-2 gap {gaps.min():.4f}")
+    rec = {}
+    with torch.no_grad():
+        otoks = O.generate_batch(sd, lmp, prefix, N_STEPS, 0.8, 1.0, 0, record=rec).numpy()
+    assert np.array_equal(otoks, toks), (otoks, toks)
+    d = maxdiff(torch.stack(rec["logits"]), L)
+    print(f"oracle logits vs reference: {d[0]:.3e} abs")
+    assert d[0] < 2e-3
+
+    # EOS semantics: stop id := token row 0 produced at step 3 -> B=1 run must break right after it
+    stop = int(toks[0, 3])
+    with torch.no_grad():
+        s_eos, t_eos, _ = ref_generate_tokens(model, prefix[:1], N_STEPS, stop_id=stop)
+        s_eos2, t_eos2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=stop)
+    print("eos case:", stop, t_eos, [len(t) for t in t_eos2])
+    np.savez_compressed(
+        os.path.join(args.out, "gen.npz"),
+        seed=SEED, B=B, steps=N_STEPS, tokens=toks, logits_sub=L[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB,
+        logits_step0=L[0].numpy(), top2_gap=gaps,
+        eos_stop_id=stop, eos_b1_tokens=np.asarray(t_eos[0], dtype=np.int64),
+        eos_b2_len=np.asarray([len(t) for t in t_eos2], dtype=np.int64),
+        eos_b2_row0=np.asarray(t_eos2[0], dtype=np.int64), eos_b2_row1=np.asarray(t_eos2[1], dtype=np.int64),
+    )
+
+    # ------------------------------------------------------------------ case "long30": 30 s -> 7 crops
+    if not args.skip_long:
+        a30 = torch.from_numpy(synth.make_clip(900, 960000))[None]
+        with torch.no_grad():
+            proj_ref, _, od = model.audio_encoder(a30)
+            ot = {}
+            proj_or = O.audio_encoder(sd, a30, ot)
+        d = maxdiff(proj_or, proj_ref)
+        print(f"long30: crops={ot.get('n_crops')} oracle vs reference projected {d[0]:.3e}")
+        assert ot["n_crops"] == 7 and d[1] < 1e-4
+        fw = od["framewise_output"]
+        np.savez_compressed(
+            os.path.join(args.out, "long30.npz"),
+            clip_idx=900, n_samples=960000, n_crops=7,
+            latent=od["latent_output"].numpy(), framewise32=fw[:, 0::32, :].numpy(),
+            audio_ds=O.downsample(proj_ref).numpy(),
+        )
+    print(f"done ({time.time() - t0:.1f}s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""CPU: the oracle (oracle/mellow_oracle.py) against the golden vectors generated from the imported
+reference (tests/golden/make_golden.py).  Sized to run in about a minute."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mellow_amd import spec, synth
+from oracle import mellow_oracle as O
+
+
+def _close(a, b, rtol=1e-5, atol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() + 1e-30
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= atol + rtol * scale, (np.abs(a - b).max(), scale)
+
+
+@pytest.fixture(scope="module")
+def enc_taps(synth_sd):
+    a1, a2, ids = synth.make_batch(2)
+    taps = {}
+    with torch.no_grad():
+        prefix = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1), torch.from_numpy(a2),
+                                             torch.from_numpy(ids), taps)
+    return prefix, taps
+
+
+def test_checkpoint_layout(synth_sd):
+    layout = spec.state_dict_layout()
+    assert len(layout) == 479                       # SURVEY.md §8b probe of the reference state_dict
+    n = sum(int(np.prod(s)) for k, (s, d) in layout.items()
+            if d == "f32" and not k.endswith(("running_mean", "running_var", "attn_mask"))
+            and k != spec.LM + "lm_head.weight")
+    assert n == 167020951                           # README.md:4 "167M" (parameters only, tied head once)
+    for k, (shape, dt) in layout.items():
+        assert tuple(synth_sd[k].shape) == shape
+        assert synth_sd[k].dtype == (torch.float32 if dt == "f32" else torch.int64)
+
+
+def test_encoder_taps_match_reference_golden(enc_taps, golden_dir):
+    prefix, t = enc_taps
+    g = np.load(os.path.join(golden_dir, "enc10.npz"))
+    _close(t["power"][:, 0, ::50, ::8], g["power_sub"], rtol=1e-6)
+    _close(t["logmel"][:, 0], g["logmel"], rtol=1e-6)
+    _close(t["logmel_bn"][:, 0, ::10, :], g["logmel_bn_sub"], rtol=1e-6)
+    _close(t["patch"][:, g["tok_idx"], :], g["patch_sub"])
+    _close(t["stage0"][:, ::11, :], g["stage0_sub"])
+    _close(t["stage1"][:, ::5, :], g["stage1_sub"])
+    _close(t["stage2"], g["stage2"])
+    _close(t["stage3"], g["stage3"])
+    _close(t["latent"], g["latent"])
+    _close(t["framewise"][:, 0::32, :], g["framewise32"])
+    emb33 = torch.cat((t["embedding"][:, :1], t["embedding"][:, 1::32]), 1)
+    _close(emb33, g["embedding33"])
+    pr33 = torch.cat((t["projected"][:, :1], t["projected"][:, 1::32]), 1)
+    _close(pr33, g["projected33"])
+    _close(prefix, g["prefix"])
+
+
+def test_only_33_distinct_rows(enc_taps):
+    """framewise has 32 distinct rows; pooled rows are (nearly) the picked rows."""
+    _, t = enc_taps
+    fw = t["framewise"]
+    assert torch.equal(fw[:, 0::32].repeat_interleave(32, dim=1), fw)
+    ds = O.downsample(t["projected"])
+    picked = t["projected"][:, 1::8][:, :128]
+    assert float((ds[:, 1:] - picked).abs().max()) < 1e-5
+
+
+def test_greedy_tokens_and_logits_match_reference_golden(synth_sd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    prefix = torch.from_numpy(e["prefix"])
+    steps = 4                                        # the reference loop re-forwards everything: keep it short
+    rec = {}
+    with torch.no_grad():
+        toks = O.generate_batch(synth_sd, O.LMParams(), prefix, steps, 0.8, 1.0, 0, record=rec).numpy()
+    assert np.array_equal(toks, g["tokens"][:, :steps])
+    L = torch.stack(rec["logits"]).numpy()
+    assert np.abs(L[:, :, g["sub_vocab"]] - g["logits_sub"][:steps]).max() < 2e-3
+    assert np.abs(L[0] - g["logits_step0"]).max() < 2e-3
+    # sampling parameters never change the arg-max
+    with torch.no_grad():
+        toks2 = O.generate_batch(synth_sd, O.LMParams(), prefix, 2, 0.1, 0.3, 0).numpy()
+    assert np.array_equal(toks2, g["tokens"][:, :2])
+
+
+def test_eos_semantics_match_reference_golden(synth_sd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    stop = int(g["eos_stop_id"])
+    prefix = torch.from_numpy(e["prefix"])
+    with torch.no_grad():
+        t = O.generate_batch(synth_sd, O.LMParams(), prefix[:1], 12, 0.8, 1.0, stop)
+    # B=1: the loop breaks right after the stop token (wrapper.py:247-249); text is cut before it (:254)
+    assert t.shape[1] == len(g["eos_b1_tokens"]) + 1
+    assert O.cut_at_stop(t, stop)[0] == g["eos_b1_tokens"].tolist()
+
+
+def test_long_audio_seven_crops(synth_sd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "long30.npz"))
+    wav = torch.from_numpy(synth.make_clip(int(g["clip_idx"]), int(g["n_samples"])))[None]
+    taps = {}
+    with torch.no_grad():
+        pv = O.audio_encoder(synth_sd, wav, taps)
+    assert taps["n_crops"] == 7 == len(spec.long_crop_positions(spec.frames_for(960000)))
+    _close(taps["latent"], g["latent"])
+    _close(taps["framewise"][:, 0::32], g["framewise32"])
+    _close(O.downsample(pv), g["audio_ds"])
