@@ -1,0 +1,156 @@
+/*
+ * mellow_hip.h — C ABI of libmellow_hip.so, the MI355X (gfx950) engine behind MellowWrapper.generate().
+ *
+ * This is the drop-in boundary for the reference's inference hot path.  The reference has no native
+ * interface (it is pure Python on PyTorch ATen); the seams this library replaces are the Python calls
+ * listed per function below (file:line in soham97/mellow).  Nothing in these signatures is a torch
+ * type: plain pointers, sizes and scalars, so the same library binds from ctypes (what
+ * mellow_amd/engine.py does), cffi, pybind11 or cgo.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; mellow_last_error() then returns a
+ *     thread-local message.  The Python wrapper re-raises the reference's exception types
+ *     (ValueError / AssertionError / RuntimeError) from it.
+ *   - "dev" pointers are HIP device pointers on the engine's device (caller-owned; a torch tensor's
+ *     data_ptr() is fine).  "host" pointers are ordinary host memory.
+ *   - all tensors are dense, row-major, fp32 unless marked int32.
+ *   - calls on one engine are serialised by the caller (the reference is single-threaded, blocking:
+ *     wrapper.py:212 `torch.no_grad()`, no re-entrancy).  Work is issued on the engine's private HIP
+ *     stream; every data-path call returns after that stream has drained unless stated otherwise.
+ *   - the engine owns weights, KV pages and workspaces; the caller owns inputs and outputs.
+ */
+#ifndef MELLOW_HIP_H
+#define MELLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MELLOW_ABI_VERSION 1
+
+typedef struct mellow_engine mellow_engine_t;
+
+/* Decoder LM hyper-parameters (reference: HF config.json of SmolLM2-135M fetched at decoder.py:25;
+ * kept as data in mellow_amd/config/lm_smollm2_135m.yaml) + encoder/prefix constants of v0.yaml. */
+typedef struct mellow_config {
+    int32_t abi_version;        /* must be MELLOW_ABI_VERSION */
+    int32_t vocab_size;         /* 49152 */
+    int32_t hidden_size;        /* 576  (must equal encoder d_proj, wrapper.py:62) */
+    int32_t intermediate_size;  /* 1536 */
+    int32_t num_layers;         /* 30 */
+    int32_t num_heads;          /* 9 */
+    int32_t num_kv_heads;       /* 3 */
+    int32_t head_dim;           /* 64 */
+    float   rms_norm_eps;       /* 1e-5 */
+    float   rope_theta;         /* 100000 */
+    int32_t max_positions;      /* rows of the RoPE table to build (>= 389 + max_len) */
+    int32_t text_len;           /* 129 (v0.yaml text_tokenization_len) */
+    int32_t prefix_len;         /* 389 (v0.yaml prefix_length) */
+    int32_t sep_token_id;       /* 0 (decoder.py:49) */
+} mellow_config_t;
+
+enum { MELLOW_F32 = 0, MELLOW_I32 = 1, MELLOW_I64 = 2 };
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int         mellow_abi_version(void);
+const char* mellow_last_error(void);
+/* number of HIP devices visible (0 when there is no GPU; never fails) */
+int         mellow_device_count(void);
+
+/* ---- lifetime: replaces MellowWrapper.get_model_and_tokenizer's model construction + load_state_dict
+ *      + model.to(cuda) (reference wrapper.py:59-88) ------------------------------------------------ */
+int  mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t** out);
+void mellow_engine_destroy(mellow_engine_t* e);
+
+/* Hand one checkpoint tensor to the engine under its reference state_dict key, e.g.
+ * "audio_encoder.base.htsat.layers.0.blocks.1.attn.qkv.weight".  `data` may be a host or a device
+ * pointer; the engine copies / re-tiles it into its own arena before returning.  Keys the inference
+ * path never reads are accepted and ignored (returns 0).  Unknown keys fail. */
+int  mellow_engine_load_tensor(mellow_engine_t* e, const char* key, const void* data,
+                               const int64_t* shape, int ndim, int dtype);
+/* Verifies that every tensor the hot path reads has been loaded (strict, like load_state_dict at
+ * wrapper.py:76) and builds derived tables (expanded relative-position bias, window maps, RoPE). */
+int  mellow_engine_finalize(mellow_engine_t* e);
+/* number of state_dict keys the engine requires / name of the i-th one (for loader validation) */
+int         mellow_engine_num_required(void);
+const char* mellow_engine_required_key(int i);
+
+/* ---- the hot path: replaces Mellow.generate_prefix_inference (mellow.py:100-108, called
+ *      wrapper.py:285) + MellowWrapper._generate_batch (wrapper.py:197-249) -------------------------
+ * audio1/audio2 : dev f32 [B][n_samples]  (what preprocess_audio returns, wrapper.py:170-179)
+ * input_ids     : dev i32 [B][text_len]   (preprocess_text's input_ids, wrapper.py:181-195)
+ * max_len       : entry_length of the loop (wrapper.py:200)
+ * top_p, temperature : accepted for API parity; the reference's filter never removes the arg-max
+ *                 (wrapper.py:220-232) so the result is greedy for every value
+ * stop_id       : tokenizer.encode(stop_token)[0] (wrapper.py:208)
+ * ignore_stop   : 0 = reference semantics (loop ends when every row has produced stop_id,
+ *                 wrapper.py:247-249); 1 = always run max_len steps (fixed-work benchmark mode)
+ * out_tokens    : dev i32 [B][max_len]; columns >= *out_steps are undefined
+ * out_len       : host i32 [B], tokens before the row's first stop_id (the text cut of wrapper.py:254)
+ * out_steps     : host, number of loop iterations the reference would have run
+ * first_token_ms: host, time from call entry until the first token id of every row is on the device
+ */
+int  mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
+                     const int32_t* input_ids, int B, int max_len, float top_p, float temperature,
+                     int stop_id, int ignore_stop, int32_t* out_tokens, int32_t* out_len,
+                     int32_t* out_steps, float* first_token_ms);
+
+/* ---- parity taps (same kernels as mellow_generate, stage by stage) ------------------------------- */
+/* A1-A3: htsat.py:864-870.  wav dev [n][n_samples] -> out dev [n][frames][64]; apply_bn=0 gives the
+ * LogmelFilterBank output, 1 the post-bn0 tensor. */
+int  mellow_logmel(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_samples, int apply_bn,
+                   float* out);
+/* A1-A13: AudioEncoder.forward (mellow.py:64-68) + downsample (decoder.py:14-18):
+ * wav dev [n][n_samples] -> out dev [n][129][576]. */
+int  mellow_encode(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_samples, float* out);
+/* A1-A14: generate_prefix_inference -> out dev [B][prefix_len][hidden]. */
+int  mellow_prefix(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
+                   const int32_t* input_ids, int B, float* out);
+/* A15 prefill: lm(inputs_embeds=prefix).logits[:, -1, :] (wrapper.py:217-218) with the KV pages
+ * written.  prefix dev [B][T][hidden]; reserve = max extra tokens that will follow; logits dev [B][vocab]
+ * (may be NULL). */
+int  mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int reserve, float* logits);
+/* A15 decode step: append embed_tokens(token_ids) (wrapper.py:237) at the next position and return the
+ * new last-position logits.  token_ids dev i32 [B]; logits dev [B][vocab] (may be NULL). */
+int  mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* logits);
+/* arg-max with first-index ties (torch.argmax, wrapper.py:232): logits dev [B][vocab] -> tokens dev i32 [B] */
+int  mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* tokens);
+
+/* Copy a named internal activation of the LAST mellow_encode / mellow_prefix call to `out` (dev).
+ * Taps are recorded only after mellow_debug_enable_taps(e, 1).  Names: "power", "logmel_bn", "patch",
+ * "stage0".."stage3", "latent", "fpx", "emb33", "proj33".  *numel receives the element count. */
+int  mellow_debug_enable_taps(mellow_engine_t* e, int on);
+int  mellow_debug_tap(mellow_engine_t* e, const char* name, float* out, int64_t capacity, int64_t* numel);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * Per-kernel-family accounting with HIP events on the engine's stream.  When enabled, every launch
+ * of a profiled family is bracketed by an event pair and its algorithmic work is accumulated;
+ * hipGraph replay is switched off while profiling (events cannot be interleaved into a replay).
+ * families: see mellow_prof_family_name(). */
+int         mellow_prof_enable(mellow_engine_t* e, int on);
+int         mellow_prof_reset(mellow_engine_t* e);
+int         mellow_prof_num_families(void);
+const char* mellow_prof_family_name(int i);
+/* launches, total milliseconds, algorithmic flops and algorithmic bytes accumulated for family i */
+int         mellow_prof_get(mellow_engine_t* e, int i, int64_t* launches, double* ms, double* flops,
+                            double* bytes);
+/* phase wall times of the last mellow_generate call (HIP events): front-end+encoder+prefix, prefill,
+ * decode loop; milliseconds */
+int         mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms, float* decode_ms);
+/* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
+int         mellow_set_graph(mellow_engine_t* e, int on);
+
+/* ---- host-only helpers (callable without a GPU; used by CPU tests) -------------------------------- */
+/* token permutation of a Swin block: out[m] = source token (h*R+w) feeding window-order row m, for
+ * resolution R and cyclic shift `shift` (htsat.py:427-436).  out host i32 [R*R]. */
+int  mellow_host_window_map(int R, int shift, int32_t* out);
+/* packs a row-major [N][K] fp32 matrix into the engine's MFMA fragment order:
+ * out host f32 [NP/32][KP/8][64][4] with NP = roundup(N,npad), KP = roundup(K,32), zero padded. */
+int  mellow_host_pack_weight(const float* w, int N, int K, int npad, float* out, int64_t out_capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELLOW_HIP_H */

@@ -1,0 +1,425 @@
+// Non-GEMM kernels of the audio encoder.  All are HBM-bound
+// index-math kernels: permutations of the reference (reflect pad, bicubic resample + 4x256 fold,
+// cyclic shift + window partition, patch-merging gather, un-fold for the token-semantic head) are
+// address arithmetic on loads, never materialised copies.
+#include "common.h"
+#include "kernels.h"
+
+namespace mellow {
+
+// ---- A1 reflect pad (torchlibrosa STFT center=True, pad_mode='reflect'; htsat.py:640-641) -----------
+__global__ void reflect_pad_kernel(const float* __restrict__ wav, int64_t n, float* __restrict__ out, int64_t plen,
+                                   int pad) {
+    const int c = blockIdx.y;
+    const float* src = wav + (int64_t)c * n;
+    float* dst = out + (int64_t)c * plen;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < plen; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t j = i - pad;
+        if (j < 0) j = -j;
+        if (j >= n) j = 2 * (n - 1) - j;
+        if (j < 0) j = 0;           // only reachable for the tail padding beyond the reflected region
+        if (j >= n) j = n - 1;
+        dst[i] = src[j];
+    }
+}
+void launch_reflect_pad(const float* wav, int n_clips, int64_t n_samples, float* out, int64_t padded_len, int pad,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(512, n_clips), dim3(256), 0, s, wav, n_samples, out, padded_len, pad);
+}
+
+// ---- A4 + A5: bicubic time resample (align_corners) + fold + 4x4 patch conv + LayerNorm(96) -----------
+// reference htsat.py:830-845 (reshape_wav2img) and :86-116 (PatchEmbed).  One wave per output token.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ __launch_bounds__(256) void fold_patch_embed_kernel(const float* __restrict__ lm, int src_frames,
+                                                               int n_crops, int crop_hop, int crop_len,
+                                                               const float* __restrict__ cw,
+                                                               const float* __restrict__ cb,
+                                                               const float* __restrict__ lw,
+                                                               const float* __restrict__ lb, float* __restrict__ x0,
+                                                               int64_t n_tokens) {
+    __shared__ float px[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + wave;
+    if (tok >= n_tokens) return;
+    const int v = (int)(tok >> 12);               // virtual clip
+    const int t = (int)(tok & 4095);
+    const int th = t >> 6, tw = t & 63;           // token row (freq-folded), token column (time)
+    const int src = v / n_crops, crop = v % n_crops;
+    const float* base = lm + ((int64_t)src * src_frames + (int64_t)crop * crop_hop) * 64;
+    if (lane < 16) {
+        const int dy = lane >> 2, dx = lane & 3;
+        const int row = th * 4 + dy;              // 0..255 = chunk*64 + mel
+        const int chunk = row >> 6, mel = row & 63;
+        const int tt = chunk * 256 + tw * 4 + dx; // destination frame 0..1023
+        float val;
+        if (crop_len == 1024) {
+            val = base[(int64_t)tt * 64 + mel];
+        } else {
+            // upsample_bicubic2d, align_corners=True: scale = (in-1)/(out-1) in fp32, A = -0.75
+            const float scale = (float)(crop_len - 1) / (float)(1024 - 1);
+            const float real = scale * (float)tt;
+            int i0 = (int)floorf(real);
+            i0 = i0 < crop_len - 1 ? i0 : crop_len - 1;
+            float lam = real - (float)i0;
+            lam = fminf(fmaxf(lam, 0.f), 1.f);
+            const float A = -0.75f;
+            const float w0 = cubic2(lam + 1.f, A), w1 = cubic1(lam, A);
+            const float w2 = cubic1(1.f - lam, A), w3 = cubic2(2.f - lam, A);
+            int i[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int ii = i0 - 1 + k;
+                ii = ii < 0 ? 0 : (ii > crop_len - 1 ? crop_len - 1 : ii);
+                i[k] = ii;
+            }
+            val = __fmul_rn(base[(int64_t)i[0] * 64 + mel], w0);
+            val = __fadd_rn(val, __fmul_rn(base[(int64_t)i[1] * 64 + mel], w1));
+            val = __fadd_rn(val, __fmul_rn(base[(int64_t)i[2] * 64 + mel], w2));
+            val = __fadd_rn(val, __fmul_rn(base[(int64_t)i[3] * 64 + mel], w3));
+        }
+        px[wave][lane] = val;
+    }
+    __syncthreads();   // n_tokens is a multiple of 4, so no wave of a block has returned early
+    float v0 = 0.f, v1 = 0.f;
+    {
+        const int o0 = lane, o1 = lane + 64;
+        float a0 = cb[o0];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) a0 += px[wave][p] * cw[o0 * 16 + p];
+        v0 = a0;
+        if (o1 < 96) {
+            float a1 = cb[o1];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) a1 += px[wave][p] * cw[o1 * 16 + p];
+            v1 = a1;
+        }
+    }
+    const bool has1 = lane < 32;
+    const float mean = wave_sum(v0 + (has1 ? v1 : 0.f)) * (1.0f / 96.0f);
+    const float d0 = v0 - mean, d1 = has1 ? v1 - mean : 0.f;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / 96.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float* dst = x0 + tok * 96;
+    dst[lane] = d0 * rstd * lw[lane] + lb[lane];
+    if (has1) dst[lane + 64] = d1 * rstd * lw[lane + 64] + lb[lane + 64];
+}
+void launch_fold_patch_embed(const float* logmel_bn, int n_src, int src_frames, int n_crops, int crop_hop,
+                             int crop_len, const float* conv_w, const float* conv_b, const float* ln_w,
+                             const float* ln_b, float* x0, hipStream_t s) {
+    const int64_t n_tokens = (int64_t)n_src * n_crops * 4096;
+    hipLaunchKernelGGL(fold_patch_embed_kernel, dim3((unsigned)((n_tokens + 3) / 4)), dim3(256), 0, s, logmel_bn,
+                       src_frames, n_crops, crop_hop, crop_len, conv_w, conv_b, ln_w, ln_b, x0, n_tokens);
+}
+
+// ---- LayerNorm family: one wave per row, row kept in registers (C <= 1536) ------------------------------
+constexpr int LN_MAXV = 6;  // float4 per lane
+
+template <int MODE>  // 0: plain / row-map gather, 1: patch-merging gather
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int64_t M, int C, const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        const int32_t* __restrict__ row_map, int ntok, int R,
+                                                        int Cin) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const int nv = C >> 2;
+    const float* src_row = nullptr;
+    int64_t seg_base[4];
+    if (MODE == 0) {
+        int64_t src = m;
+        if (row_map) src = (m / ntok) * ntok + row_map[m % ntok];
+        src_row = in + src * C;
+    } else {
+        // output token (clip, i, j) of the (R/2)^2 grid gathers tokens (2i,2j), (2i+1,2j), (2i,2j+1), (2i+1,2j+1)
+        // in that order (reference htsat.py:488-492)
+        const int R2 = R >> 1;
+        const int64_t clip = m / (R2 * R2);
+        const int ij = (int)(m % (R2 * R2));
+        const int i = ij / R2, j = ij % R2;
+        const int64_t cb = clip * R * R;
+        seg_base[0] = (cb + (int64_t)(2 * i) * R + 2 * j) * Cin;
+        seg_base[1] = (cb + (int64_t)(2 * i + 1) * R + 2 * j) * Cin;
+        seg_base[2] = (cb + (int64_t)(2 * i) * R + 2 * j + 1) * Cin;
+        seg_base[3] = (cb + (int64_t)(2 * i + 1) * R + 2 * j + 1) * Cin;
+    }
+    float4 x[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + 64 * q;
+        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < nv) {
+            if (MODE == 0) {
+                x[q] = reinterpret_cast<const float4*>(src_row)[v];
+            } else {
+                const int e = v * 4;
+                const int seg = e / Cin, c = e % Cin;
+                x[q] = *reinterpret_cast<const float4*>(in + seg_base[seg] + c);
+            }
+            sum += (x[q].x + x[q].y) + (x[q].z + x[q].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + 64 * q;
+        if (v < nv) {
+            const float a = x[q].x - mean, bb = x[q].y - mean, c = x[q].z - mean, d = x[q].w - mean;
+            sq += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + 1e-5f);
+    float4* dst = reinterpret_cast<float4*>(out + m * C);
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + 64 * q;
+        if (v < nv) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[v];
+            const float4 bv = reinterpret_cast<const float4*>(b)[v];
+            float4 y;
+            y.x = (x[q].x - mean) * rstd * ww.x + bv.x;
+            y.y = (x[q].y - mean) * rstd * ww.y + bv.y;
+            y.z = (x[q].z - mean) * rstd * ww.z + bv.z;
+            y.w = (x[q].w - mean) * rstd * ww.w + bv.w;
+            dst[v] = y;
+        }
+    }
+}
+void launch_layernorm(const float* in, float* out, int M, int C, const float* w, const float* b,
+                      const int32_t* row_map, int ntok, hipStream_t s) {
+    hipLaunchKernelGGL((layernorm_kernel<0>), dim3((M + 3) / 4), dim3(256), 0, s, in, out, (int64_t)M, C, w, b,
+                       row_map, ntok, 0, 0);
+}
+void launch_merge_layernorm(const float* in, float* out, int n, int R, int C, const float* w, const float* b,
+                            hipStream_t s) {
+    const int64_t M = (int64_t)n * (R / 2) * (R / 2);
+    hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, in, out, M, 4 * C, w, b,
+                       (const int32_t*)nullptr, 0, R, C);
+}
+
+// LlamaRMSNorm (fp32): w * (x * rsqrt(mean(x^2) + eps))
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t M,
+                                                      int C, const float* __restrict__ w, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const int nv = C >> 2;
+    const float4* src = reinterpret_cast<const float4*>(in + m * C);
+    float4 x[LN_MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + 64 * q;
+        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < nv) {
+            x[q] = src[v];
+            ss += (x[q].x * x[q].x + x[q].y * x[q].y) + (x[q].z * x[q].z + x[q].w * x[q].w);
+        }
+    }
+    const float r = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    float4* dst = reinterpret_cast<float4*>(out + m * C);
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + 64 * q;
+        if (v < nv) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[v];
+            float4 y;
+            y.x = __fmul_rn(ww.x, __fmul_rn(x[q].x, r));
+            y.y = __fmul_rn(ww.y, __fmul_rn(x[q].y, r));
+            y.z = __fmul_rn(ww.z, __fmul_rn(x[q].z, r));
+            y.w = __fmul_rn(ww.w, __fmul_rn(x[q].w, r));
+            dst[v] = y;
+        }
+    }
+}
+void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, out, (int64_t)M, C, w, eps);
+}
+
+// ---- A7 window attention core: one wave per (window, head), lane = query token -------------------------------
+// reference htsat.py:301-327.  Inputs arrive in window order (the LN kernel did roll + partition), so a
+// window is 64 consecutive rows.  q/k/v of one head are 64x24: K and V sit in LDS (6 KiB each) and are
+// read as broadcasts; the lane keeps its 64 scores, softmax is entirely in-lane.
+__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                               int C, int nH, const float* __restrict__ bias_exp,
+                                                               const float* __restrict__ mask, int nW,
+                                                               int64_t n_tiles) {
+    __shared__ __attribute__((aligned(16))) float Ks[4][64 * 24];
+    __shared__ __attribute__((aligned(16))) float Vs[4][64 * 24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;   // tile = window * nH + head
+    const bool active = tile < n_tiles;
+    const int64_t win = active ? tile / nH : 0;
+    const int hd = active ? (int)(tile % nH) : 0;
+    const float* row = qkv + (win * 64 + lane) * (3 * C) + hd * 24;
+    float q[24];
+    {
+        const float scale = 0.20412414523193150818f;  // 24^-0.5 (python float -> fp32 scalar multiply)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const float4 t = *reinterpret_cast<const float4*>(row + v * 4);
+            q[4 * v] = t.x * scale; q[4 * v + 1] = t.y * scale; q[4 * v + 2] = t.z * scale; q[4 * v + 3] = t.w * scale;
+            *reinterpret_cast<float4*>(&Ks[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(row + C + v * 4);
+            *reinterpret_cast<float4*>(&Vs[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(row + 2 * C + v * 4);
+        }
+    }
+    __syncthreads();
+    float s[64];
+    const float* brow = bias_exp + ((int64_t)hd * 64 + lane) * 64;
+    const float* mrow = mask ? mask + ((win % nW) * 64 + lane) * 64 : nullptr;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float* kj = &Ks[wave][j * 24];
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < 24; ++d) a = fmaf(q[d], kj[d], a);
+        a = a + brow[j];
+        if (mrow) a = a + mrow[j];
+        s[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        s[j] = expf(s[j] - mx);
+        sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+    float o[24];
+#pragma unroll
+    for (int d = 0; d < 24; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float p = s[j] * inv;
+        const float* vj = &Vs[wave][j * 24];
+#pragma unroll
+        for (int d = 0; d < 24; ++d) o[d] = fmaf(p, vj[d], o[d]);
+    }
+    if (active) {
+        float* dst = out + (win * 64 + lane) * C + hd * 24;
+#pragma unroll
+        for (int v = 0; v < 6; ++v)
+            *reinterpret_cast<float4*>(dst + v * 4) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
+    }
+}
+void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
+                             const float* mask, int nW, hipStream_t s) {
+    const int64_t n_tiles = (int64_t)(M / 64) * nH;
+    hipLaunchKernelGGL(window_attention_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+                       bias_exp, mask, nW, n_tiles);
+}
+
+// ---- A10 tail: latent mean + im2col for the token-semantic conv (htsat.py:742-775) ---------------------------
+// y [n][64][768], token = F*8 + T with F = g*2 + cf (g = time group 0..3, cf = freq bin 0..1).
+// regrouped time index tt = g*8 + T (0..31).  a_ts row (clip, tt), column (cf*3 + dt)*768 + ch holds
+// y[clip][token(g', cf, T')][ch] with tt' = tt + dt - 1 (zero outside 0..31).
+__global__ __launch_bounds__(256) void tail_latent_im2col_kernel(const float* __restrict__ y, float* __restrict__ latent,
+                                                                 int64_t latent_stride, float* __restrict__ a_ts) {
+    const int clip = blockIdx.x;
+    const float* yc = y + (int64_t)clip * 64 * 768;
+    // latent: mean over the 64 positions in (cf, tt) order, like avgpool(flatten(x, 2))
+    for (int ch = threadIdx.x; ch < 768; ch += 256) {
+        float sacc = 0.f;
+        for (int cf = 0; cf < 2; ++cf)
+            for (int tt = 0; tt < 32; ++tt) {
+                const int tok = ((tt >> 3) * 2 + cf) * 8 + (tt & 7);
+                sacc += yc[tok * 768 + ch];
+            }
+        latent[(int64_t)clip * latent_stride + ch] = sacc * (1.0f / 64.0f);
+    }
+    // im2col
+    float4* dst = reinterpret_cast<float4*>(a_ts + (int64_t)clip * 32 * 4608);
+    for (int i = threadIdx.x; i < 32 * 6 * 192; i += 256) {
+        const int c4 = i % 192;
+        const int seg = (i / 192) % 6;
+        const int tt = i / (192 * 6);
+        const int cf = seg / 3, dt = seg % 3;
+        const int ts = tt + dt - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ts >= 0 && ts < 32) {
+            const int tok = ((ts >> 3) * 2 + cf) * 8 + (ts & 7);
+            v = reinterpret_cast<const float4*>(yc + tok * 768)[c4];
+        }
+        dst[(int64_t)tt * 1152 + seg * 192 + c4] = v;
+    }
+}
+void launch_tail_latent_im2col(const float* y, int n, float* latent, int64_t latent_stride, float* a_ts,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(tail_latent_im2col_kernel, dim3(n), dim3(256), 0, s, y, latent, latent_stride, a_ts);
+}
+
+// mean over crops, summed sequentially from zero then divided (htsat.py:922-931)
+__global__ void crop_average_kernel(const float* __restrict__ in, int n_crops, int64_t len, int64_t in_stride,
+                                    float* __restrict__ out, int64_t out_stride) {
+    const int c = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int k = 0; k < n_crops; ++k) a = __fadd_rn(a, in[((int64_t)c * n_crops + k) * in_stride + i]);
+        out[(int64_t)c * out_stride + i] = a / (float)n_crops;
+    }
+}
+void launch_crop_average(const float* in, int n, int n_crops, int64_t len, int64_t in_stride, float* out,
+                         int64_t out_stride, hipStream_t s) {
+    hipLaunchKernelGGL(crop_average_kernel, dim3(64, n), dim3(256), 0, s, in, n_crops, len, in_stride, out, out_stride);
+}
+
+__global__ void gelu_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = gelu_erf(in[i]);
+}
+void launch_gelu(const float* in, float* out, int64_t n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gelu_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+}
+
+// ---- A13 + A14: downsample + prefix assembly (decoder.py:14-18, 36-55) ----------------------------------------
+// pooled row j (0..127) averages framewise rows 8j..8j+7 = eight copies of distinct row j/4; the 8-term
+// sequential sum + divide is reproduced so the rounding matches avg_pool2d.
+__device__ __forceinline__ float pool8(float a) {
+    float s = a;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s = __fadd_rn(s, a);
+    return s * 0.125f;
+}
+__device__ __forceinline__ float audio_row_value(const float* __restrict__ p33, int r, int c) {
+    // r in 0..128 of the 129-row downsampled audio embedding; p33 -> [33][576] of one clip
+    if (r == 0) return p33[c];
+    return pool8(p33[(1 + ((r - 1) >> 2)) * 576 + c]);
+}
+__global__ __launch_bounds__(192) void prefix_assemble_kernel(const float* __restrict__ proj33,
+                                                              const float* __restrict__ embed,
+                                                              const int32_t* __restrict__ ids, int B, int text_len,
+                                                              int sep_id, float* __restrict__ prefix) {
+    const int pos = blockIdx.x, b = blockIdx.y;
+    const int P = 2 * 129 + 2 + text_len;
+    float* dst = prefix + ((int64_t)b * P + pos) * 576;
+    for (int c = threadIdx.x; c < 576; c += 192) {
+        float v;
+        if (pos < 129) v = audio_row_value(proj33 + (int64_t)b * 33 * 576, pos, c);
+        else if (pos == 129) v = embed[(int64_t)sep_id * 576 + c];
+        else if (pos < 259) v = audio_row_value(proj33 + (int64_t)(B + b) * 33 * 576, pos - 130, c);
+        else if (pos == 259) v = embed[(int64_t)sep_id * 576 + c];
+        else v = embed[(int64_t)ids[(int64_t)b * text_len + (pos - 260)] * 576 + c];
+        dst[c] = v;
+    }
+}
+void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
+                            int sep_id, float* prefix, hipStream_t s) {
+    hipLaunchKernelGGL(prefix_assemble_kernel, dim3(260 + text_len, B), dim3(192), 0, s, proj33, embed, ids, B,
+                       text_len, sep_id, prefix);
+}
+__global__ __launch_bounds__(192) void downsample33_kernel(const float* __restrict__ proj33, float* __restrict__ out) {
+    const int r = blockIdx.x, clip = blockIdx.y;
+    for (int c = threadIdx.x; c < 576; c += 192)
+        out[((int64_t)clip * 129 + r) * 576 + c] = audio_row_value(proj33 + (int64_t)clip * 33 * 576, r, c);
+}
+void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(downsample33_kernel, dim3(129, n), dim3(192), 0, s, proj33, out);
+}
+
+}  // namespace mellow

@@ -1,0 +1,1210 @@
+// Host side of libmellow_hip.so: the C ABI of include/mellow_hip.h.
+// Owns weights (re-tiled into MFMA fragment order at load), KV pages, workspaces, the private HIP
+// stream, the captured decode-step hipGraph and the event-based profiler.
+//
+// Reference seams replaced (soham97/mellow):
+//   model construction + load_state_dict + .to(cuda)      wrapper.py:59-88      -> create/load/finalize
+//   Mellow.generate_prefix_inference                      mellow.py:100-108     -> run_encoder + prefix
+//   MellowWrapper._generate_batch                         wrapper.py:197-249    -> mellow_generate
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mellow_hip.h"
+#include "kernels.h"
+
+using namespace mellow;
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)            \
+    do {                     \
+        int _r = (expr);     \
+        if (_r) return _r;   \
+    } while (0)
+
+// ---- model constants (reference mellow/model/config.py:1-10, htsat.py:599-606) ---------------------------
+static const int kDepths[4] = {2, 2, 6, 2};
+static const int kHeads[4] = {4, 8, 16, 32};
+static const int kWin = 8;
+static const int kHop = 320, kNfft = 1024, kNfreq = 513, kMel = 64;
+static const int kClasses = 527, kEncOut = 768, kProj = 576;
+static const int kLongCrop = 689, kLongHop = 344;
+static const char* ENC = "audio_encoder.base.htsat.";
+static const char* C2L = "audio_encoder.base.c2l.";
+static const char* PRJ = "audio_encoder.projection.";
+static const char* LMK = "caption_decoder.lm.";
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- profiler families --------------------------------------------------------------------------------------
+enum { PF_GEMM = 0, PF_SKINNY, PF_PREFILL_ATTN, PF_DECODE_ATTN, PF_WINDOW_ATTN, PF_NORM, PF_MISC, PF_COUNT };
+static const char* kFamilyNames[PF_COUNT] = {"gemm_f32_mfma", "skinny_gemm_m32", "prefill_attention",
+                                             "decode_attention", "window_attention", "norm", "misc"};
+
+struct HostTensor {
+    std::vector<char> data;
+    std::vector<int64_t> shape;
+    int dtype = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : shape) n *= d;
+        return n;
+    }
+    const float* f() const { return reinterpret_cast<const float*>(data.data()); }
+};
+
+struct Packed {  // a P-layout weight
+    float* p = nullptr;
+    int N = 0, K = 0, NP = 0, KP = 0;
+    int Nw = 0;  // logical packed rows (pairs: 64*ceil(N/32))
+};
+
+struct SwinBlockW {
+    float *n1w, *n1b, *n2w, *n2b;
+    Packed qkv, proj, fc1, fc2;
+    float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    float* bias_exp;  // [nH][64][64]
+    float* mask;      // [nW][64][64] or null
+};
+struct MergeW {
+    float *nw, *nb;
+    Packed red;
+};
+struct LMLayerW {
+    Packed qkv, o, gateup, down;
+    float *in_ln, *post_ln;
+};
+
+struct ProfRec {
+    int fam;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+
+struct mellow_engine {
+    mellow_config_t cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;   // until finalize
+    std::vector<void*> allocs;                // everything hipMalloc'd for weights
+
+    // encoder weights
+    Packed dft, mel;
+    float *bn_alpha = nullptr, *bn_beta = nullptr;
+    float *pe_w = nullptr, *pe_b = nullptr, *pe_nw = nullptr, *pe_nb = nullptr;
+    std::vector<SwinBlockW> blocks[4];
+    MergeW merge[3];
+    int32_t* win_map[4][2] = {{nullptr}};     // [stage][shifted]
+    float *fn_w = nullptr, *fn_b = nullptr;
+    Packed tscam, c2l, lin1, lin2;
+    float *tscam_b = nullptr, *c2l_b = nullptr, *pln_w = nullptr, *pln_b = nullptr;
+    int32_t* emb_row_map = nullptr;           // {1..32}
+    // LM
+    float* embed = nullptr;                   // row-major [V][H]
+    Packed lm_head;
+    std::vector<LMLayerW> layers;
+    float* final_norm = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+
+    // workspaces (grow-only)
+    struct Buf {
+        float* p = nullptr;
+        size_t cap = 0;
+    };
+    Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
+    Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
+    Buf dx, dqkv, dattn, dgu, dlogits;
+    int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
+    int kv_B = 0, kv_Tmax = 0;                // current page geometry
+    int cur_B = 0, cur_pos = 0;               // host mirror of the decode state
+
+    // taps
+    bool taps_on = false;
+    std::map<std::string, Buf> taps;
+    std::map<std::string, int64_t> tap_numel;
+
+    // graph
+    bool use_graph = true;
+    hipGraphExec_t step_exec = nullptr;
+    int step_exec_B = -1, step_exec_Tmax = -1;
+    int32_t* graph_out_tokens = nullptr;
+    int graph_max_len = -1, graph_stop = -1;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
+    float phase_ms[3] = {0, 0, 0};
+};
+
+// ---- small helpers ---------------------------------------------------------------------------------------------
+static int ensure(mellow_engine* e, mellow_engine::Buf& b, size_t floats) {
+    if (b.cap >= floats) return 0;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIPCHK(hipMalloc(&b.p, floats * sizeof(float)));
+    b.cap = floats;
+    return 0;
+}
+static int dev_alloc(mellow_engine* e, float** out, size_t floats) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, floats * sizeof(float)));
+    e->allocs.push_back(p);
+    *out = reinterpret_cast<float*>(p);
+    return 0;
+}
+static int upload(mellow_engine* e, float** out, const float* src, size_t floats, size_t alloc_floats = 0) {
+    if (alloc_floats < floats) alloc_floats = floats;
+    CHK(dev_alloc(e, out, alloc_floats));
+    if (alloc_floats > floats) HIPCHK(hipMemsetAsync(*out, 0, alloc_floats * sizeof(float), e->stream));
+    HIPCHK(hipMemcpyAsync(*out, src, floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+static hipEvent_t next_event(mellow_engine* e) {
+    if (e->ev_used == e->ev_pool.size()) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[e->ev_used++];
+}
+struct ProfScope {
+    mellow_engine* e;
+    ProfRec r;
+    bool on;
+    ProfScope(mellow_engine* e_, int fam, double flops, double bytes) : e(e_), on(e_->prof_on) {
+        if (on) {
+            r.fam = fam;
+            r.flops = flops;
+            r.bytes = bytes;
+            r.a = next_event(e);
+            r.b = next_event(e);
+            hipEventRecord(r.a, e->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(r.b, e->stream);
+            e->prof.push_back(r);
+        }
+    }
+};
+
+static int tap(mellow_engine* e, const char* name, const float* src, int64_t n) {
+    if (!e->taps_on) return 0;
+    auto& b = e->taps[name];
+    CHK(ensure(e, b, (size_t)n));
+    HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    e->tap_numel[name] = n;
+    return 0;
+}
+
+// ---- required keys ---------------------------------------------------------------------------------------------------
+static std::vector<std::string> build_required(const mellow_config_t* cfg) {
+    std::vector<std::string> k;
+    std::string E = ENC;
+    k.push_back(E + "spectrogram_extractor.stft.conv_real.weight");
+    k.push_back(E + "spectrogram_extractor.stft.conv_imag.weight");
+    k.push_back(E + "logmel_extractor.melW");
+    for (const char* s : {"weight", "bias", "running_mean", "running_var"}) k.push_back(E + "bn0." + s);
+    k.push_back(E + "patch_embed.proj.weight");
+    k.push_back(E + "patch_embed.proj.bias");
+    k.push_back(E + "patch_embed.norm.weight");
+    k.push_back(E + "patch_embed.norm.bias");
+    for (int s = 0; s < 4; ++s) {
+        const int R = 64 >> s;
+        for (int b = 0; b < kDepths[s]; ++b) {
+            std::string p = E + "layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+            if ((b % 2 == 1) && R > kWin) k.push_back(p + "attn_mask");
+            for (const char* t : {"norm1.weight", "norm1.bias", "attn.relative_position_bias_table",
+                                  "attn.relative_position_index", "attn.qkv.weight", "attn.qkv.bias",
+                                  "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                                  "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"})
+                k.push_back(p + t);
+        }
+        if (s < 3) {
+            std::string p = E + "layers." + std::to_string(s) + ".downsample.";
+            k.push_back(p + "reduction.weight");
+            k.push_back(p + "norm.weight");
+            k.push_back(p + "norm.bias");
+        }
+    }
+    k.push_back(E + "norm.weight");
+    k.push_back(E + "norm.bias");
+    k.push_back(E + "tscam_conv.weight");
+    k.push_back(E + "tscam_conv.bias");
+    k.push_back(std::string(C2L) + "weight");
+    k.push_back(std::string(C2L) + "bias");
+    k.push_back(std::string(PRJ) + "linear1.weight");
+    k.push_back(std::string(PRJ) + "linear2.weight");
+    k.push_back(std::string(PRJ) + "layer_norm.weight");
+    k.push_back(std::string(PRJ) + "layer_norm.bias");
+    std::string L = LMK;
+    k.push_back(L + "model.embed_tokens.weight");
+    const int nl = cfg ? cfg->num_layers : 30;
+    for (int l = 0; l < nl; ++l) {
+        std::string p = L + "model.layers." + std::to_string(l) + ".";
+        for (const char* t : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                              "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                              "mlp.down_proj.weight", "input_layernorm.weight", "post_attention_layernorm.weight"})
+            k.push_back(p + t);
+    }
+    k.push_back(L + "model.norm.weight");
+    return k;
+}
+static const std::vector<std::string>& default_required() {
+    static std::vector<std::string> k = build_required(nullptr);
+    return k;
+}
+static bool is_ignored_key(const std::string& k) {
+    std::string E = ENC;
+    return k == E + "bn0.num_batches_tracked" || k == E + "head.weight" || k == E + "head.bias" ||
+           k == std::string(LMK) + "lm_head.weight";  // tied to embed_tokens
+}
+
+// ---- host-only helpers -----------------------------------------------------------------------------------------------
+static void window_map_host(int R, int shift, int32_t* out) {
+    // window-order row m = widx*64 + i*8 + j  <-  token ((hs+shift)%R)*R + (ws+shift)%R, (hs,ws) = window coords
+    const int ws = R < kWin ? R : kWin;
+    const int nwc = R / ws;
+    for (int wr = 0; wr < nwc; ++wr)
+        for (int wc = 0; wc < nwc; ++wc)
+            for (int i = 0; i < ws; ++i)
+                for (int j = 0; j < ws; ++j) {
+                    const int hs = wr * ws + i, wsx = wc * ws + j;
+                    const int m = (wr * nwc + wc) * ws * ws + i * ws + j;
+                    out[m] = ((hs + shift) % R) * R + (wsx + shift) % R;
+                }
+}
+static void pack_weight_host(const float* w, int N, int K, int NP, int KP, float* out) {
+    const int K8 = KP / 8;
+    for (int nt = 0; nt < NP / 32; ++nt)
+        for (int k8 = 0; k8 < K8; ++k8)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nt * 32 + (lane & 31), k = k8 * 8 + 4 * (lane >> 5) + j;
+                    out[(((int64_t)nt * K8 + k8) * 64 + lane) * 4 + j] = (n < N && k < K) ? w[(int64_t)n * K + k] : 0.f;
+                }
+}
+
+extern "C" {
+
+int mellow_abi_version(void) { return MELLOW_ABI_VERSION; }
+const char* mellow_last_error(void) { return g_err.c_str(); }
+int mellow_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int mellow_engine_num_required(void) { return (int)default_required().size(); }
+const char* mellow_engine_required_key(int i) {
+    const auto& k = default_required();
+    if (i < 0 || i >= (int)k.size()) return nullptr;
+    return k[i].c_str();
+}
+int mellow_prof_num_families(void) { return PF_COUNT; }
+const char* mellow_prof_family_name(int i) { return (i >= 0 && i < PF_COUNT) ? kFamilyNames[i] : nullptr; }
+
+int mellow_host_window_map(int R, int shift, int32_t* out) {
+    if (R <= 0 || (R % 8 && R > 8) || !out) return fail("bad window map arguments");
+    window_map_host(R, shift, out);
+    return 0;
+}
+int mellow_host_pack_weight(const float* w, int N, int K, int npad, float* out, int64_t out_capacity) {
+    if (!w || !out || N <= 0 || K <= 0 || npad <= 0 || npad % 32) return fail("bad pack arguments");
+    const int NP = rup(N, npad), KP = rup(K, 32);
+    if (out_capacity < (int64_t)NP * KP) return fail("pack output too small: need %lld floats", (long long)NP * KP);
+    pack_weight_host(w, N, K, NP, KP, out);
+    return 0;
+}
+
+int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t** out) {
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->abi_version != MELLOW_ABI_VERSION) return fail("ABI version mismatch: caller %d, library %d", cfg->abi_version, MELLOW_ABI_VERSION);
+    if (cfg->hidden_size != 576 || cfg->head_dim != 64 || cfg->num_heads != 9 || cfg->num_kv_heads != 3 ||
+        cfg->intermediate_size != 1536)
+        return fail("unsupported decoder geometry (engine is built for SmolLM2-135M: hidden 576, 9q/3kv heads x 64, inter 1536)");
+    if (cfg->prefix_len != 2 * 129 + 2 + cfg->text_len) return fail("prefix_len must be 2*129+2+text_len");
+    if (cfg->vocab_size % 128) return fail("vocab_size must be a multiple of 128");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("no HIP device available: the Mellow engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail("device %d out of range (%d devices)", device, n);
+    HIPCHK(hipSetDevice(device));
+    mellow_engine* e = new mellow_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
+    const char* ng = getenv("MELLOW_NO_GRAPH");
+    if (ng && ng[0] == '1') e->use_graph = false;
+    *out = e;
+    return 0;
+}
+
+void mellow_engine_destroy(mellow_engine_t* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->step_exec) hipGraphExecDestroy(e->step_exec);
+    for (void* p : e->allocs) hipFree(p);
+    mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
+                                  &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
+                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dx,
+                                  &e->dqkv, &e->dattn, &e->dgu, &e->dlogits};
+    for (auto* b : bufs)
+        if (b->p) hipFree(b->p);
+    for (auto& kv : e->taps)
+        if (kv.second.p) hipFree(kv.second.p);
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    for (int i = 0; i < 4; ++i)
+        if (e->ev_phase[i]) hipEventDestroy(e->ev_phase[i]);
+    if (e->d_tokens) hipFree(e->d_tokens);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int mellow_engine_load_tensor(mellow_engine_t* e, const char* key, const void* data, const int64_t* shape, int ndim,
+                              int dtype) {
+    if (!e || !key || !data) return fail("null argument");
+    if (e->finalized) return fail("engine already finalized");
+    std::string k = key;
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);  // DataParallel prefix (reference wrapper.py:78-82)
+    if (is_ignored_key(k)) return 0;
+    bool known = (k == "mellow.rope_cos" || k == "mellow.rope_sin");
+    if (!known) {
+        for (const auto& r : build_required(&e->cfg))
+            if (r == k) { known = true; break; }
+    }
+    if (!known) return fail("unexpected key in state_dict: %s", key);
+    HostTensor t;
+    t.dtype = dtype;
+    for (int i = 0; i < ndim; ++i) t.shape.push_back(shape[i]);
+    const size_t esz = dtype == MELLOW_I64 ? 8 : 4;
+    t.data.resize((size_t)t.numel() * esz);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(t.data.data(), data, t.data.size(), hipMemcpyDefault));
+    e->host[k] = std::move(t);
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- finalize helpers --------------------------------------------------------------------------------------------------
+static const HostTensor* get(mellow_engine* e, const std::string& k) {
+    auto it = e->host.find(k);
+    return it == e->host.end() ? nullptr : &it->second;
+}
+static int expect_shape(const HostTensor* t, const std::string& k, std::initializer_list<int64_t> shp) {
+    if (!t) return fail("missing key in state_dict: %s", k.c_str());
+    if (t->dtype != MELLOW_F32) return fail("%s: expected float32", k.c_str());
+    if (t->shape.size() != shp.size()) return fail("%s: rank mismatch", k.c_str());
+    size_t i = 0;
+    for (auto d : shp)
+        if (t->shape[i++] != d) return fail("size mismatch for %s", k.c_str());
+    return 0;
+}
+static int up_vec(mellow_engine* e, const std::string& k, int64_t n, float** out, int64_t pad_to = 0) {
+    const HostTensor* t = get(e, k);
+    CHK(expect_shape(t, k, {n}));
+    return upload(e, out, t->f(), (size_t)n, (size_t)pad_to);
+}
+// pack host row-major [N][K] (optionally two sources for pairs) into P-layout on device
+static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N, int K, Packed* out) {
+    Packed p;
+    p.N = N;
+    p.K = K;
+    p.KP = rup(K, 32);
+    p.Nw = w1 ? 64 * ((N + 31) / 32) : N;
+    p.NP = rup(p.Nw, 128);
+    float *d0 = nullptr, *d1 = nullptr;
+    HIPCHK(hipMalloc(&d0, (size_t)N * K * sizeof(float)));
+    HIPCHK(hipMemcpy(d0, w0, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice));
+    if (w1) {
+        HIPCHK(hipMalloc(&d1, (size_t)N * K * sizeof(float)));
+        HIPCHK(hipMemcpy(d1, w1, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice));
+    }
+    CHK(dev_alloc(e, &p.p, (size_t)p.NP * p.KP));
+    if (w1) launch_pack_weight_pairs(d0, d1, N, K, K, p.p, p.NP, p.KP, e->stream);
+    else launch_pack_weight(d0, N, K, K, p.p, p.NP, p.KP, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(d0));
+    if (d1) HIPCHK(hipFree(d1));
+    *out = p;
+    return 0;
+}
+static int pack_key(mellow_engine* e, const std::string& k, int N, int K, Packed* out) {
+    const HostTensor* t = get(e, k);
+    CHK(expect_shape(t, k, {N, K}));
+    return make_packed(e, t->f(), nullptr, N, K, out);
+}
+
+extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
+    if (!e) return fail("null engine");
+    if (e->finalized) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    for (const auto& k : build_required(&e->cfg))
+        if (!get(e, k)) return fail("missing key in state_dict: %s", k.c_str());
+    const std::string E = ENC;
+    // ---- front-end: DFT (re/im pairs), mel (transposed), bn0 as alpha/beta ----
+    {
+        const std::string kr = E + "spectrogram_extractor.stft.conv_real.weight", ki = E + "spectrogram_extractor.stft.conv_imag.weight";
+        CHK(expect_shape(get(e, kr), kr, {kNfreq, 1, kNfft}));
+        CHK(expect_shape(get(e, ki), ki, {kNfreq, 1, kNfft}));
+        CHK(make_packed(e, get(e, kr)->f(), get(e, ki)->f(), kNfreq, kNfft, &e->dft));
+        const std::string km = E + "logmel_extractor.melW";
+        CHK(expect_shape(get(e, km), km, {kNfreq, kMel}));
+        std::vector<float> mt((size_t)kMel * kNfreq);
+        const float* mw = get(e, km)->f();
+        for (int k = 0; k < kNfreq; ++k)
+            for (int n = 0; n < kMel; ++n) mt[(size_t)n * kNfreq + k] = mw[(size_t)k * kMel + n];
+        CHK(make_packed(e, mt.data(), nullptr, kMel, kNfreq, &e->mel));
+        const HostTensor *w = get(e, E + "bn0.weight"), *b = get(e, E + "bn0.bias"), *rm = get(e, E + "bn0.running_mean"),
+                         *rv = get(e, E + "bn0.running_var");
+        for (auto* t : {w, b, rm, rv})
+            if (t->numel() != kMel) return fail("size mismatch for bn0");
+        std::vector<float> al(kMel), be(kMel);
+        for (int i = 0; i < kMel; ++i) {
+            // eval BatchNorm: y = x*alpha + beta with alpha = w/sqrt(var+eps), beta = b - mean*alpha (fp32)
+            const float invstd = 1.0f / sqrtf(rv->f()[i] + 1e-5f);
+            al[i] = invstd * w->f()[i];
+            be[i] = b->f()[i] - rm->f()[i] * al[i];
+        }
+        CHK(upload(e, &e->bn_alpha, al.data(), kMel));
+        CHK(upload(e, &e->bn_beta, be.data(), kMel));
+    }
+    // ---- patch embed ----
+    {
+        const std::string k = E + "patch_embed.proj.weight";
+        CHK(expect_shape(get(e, k), k, {96, 1, 4, 4}));
+        CHK(upload(e, &e->pe_w, get(e, k)->f(), 96 * 16));
+        CHK(up_vec(e, E + "patch_embed.proj.bias", 96, &e->pe_b));
+        CHK(up_vec(e, E + "patch_embed.norm.weight", 96, &e->pe_nw));
+        CHK(up_vec(e, E + "patch_embed.norm.bias", 96, &e->pe_nb));
+    }
+    // ---- Swin stages ----
+    for (int s = 0; s < 4; ++s) {
+        const int C = 96 << s, nH = kHeads[s], R = 64 >> s, nW = (R / kWin) * (R / kWin);
+        for (int sh = 0; sh < 2; ++sh) {
+            if (R <= kWin) continue;  // single window: identity order
+            std::vector<int32_t> m((size_t)R * R);
+            window_map_host(R, sh ? kWin / 2 : 0, m.data());
+            float* d = nullptr;
+            CHK(upload(e, &d, reinterpret_cast<const float*>(m.data()), m.size()));
+            e->win_map[s][sh] = reinterpret_cast<int32_t*>(d);
+        }
+        for (int b = 0; b < kDepths[s]; ++b) {
+            const std::string p = E + "layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+            SwinBlockW w{};
+            CHK(up_vec(e, p + "norm1.weight", C, &w.n1w));
+            CHK(up_vec(e, p + "norm1.bias", C, &w.n1b));
+            CHK(up_vec(e, p + "norm2.weight", C, &w.n2w));
+            CHK(up_vec(e, p + "norm2.bias", C, &w.n2b));
+            CHK(pack_key(e, p + "attn.qkv.weight", 3 * C, C, &w.qkv));
+            CHK(pack_key(e, p + "attn.proj.weight", C, C, &w.proj));
+            CHK(pack_key(e, p + "mlp.fc1.weight", 4 * C, C, &w.fc1));
+            CHK(pack_key(e, p + "mlp.fc2.weight", C, 4 * C, &w.fc2));
+            CHK(up_vec(e, p + "attn.qkv.bias", 3 * C, &w.qkv_b, w.qkv.NP));
+            CHK(up_vec(e, p + "attn.proj.bias", C, &w.proj_b, w.proj.NP));
+            CHK(up_vec(e, p + "mlp.fc1.bias", 4 * C, &w.fc1_b, w.fc1.NP));
+            CHK(up_vec(e, p + "mlp.fc2.bias", C, &w.fc2_b, w.fc2.NP));
+            // expanded relative position bias: bias[h][i][j] = table[index[i][j]][h] (htsat.py:314-316)
+            const HostTensor *tb = get(e, p + "attn.relative_position_bias_table"), *ix = get(e, p + "attn.relative_position_index");
+            CHK(expect_shape(tb, p + "attn.relative_position_bias_table", {225, nH}));
+            if (ix->numel() != 64 * 64) return fail("size mismatch for %sattn.relative_position_index", p.c_str());
+            std::vector<float> be((size_t)nH * 4096);
+            for (int i = 0; i < 4096; ++i) {
+                int64_t id;
+                if (ix->dtype == MELLOW_I64) id = reinterpret_cast<const int64_t*>(ix->data.data())[i];
+                else id = reinterpret_cast<const int32_t*>(ix->data.data())[i];
+                if (id < 0 || id >= 225) return fail("relative_position_index out of range");
+                for (int h = 0; h < nH; ++h) be[(size_t)h * 4096 + i] = tb->f()[id * nH + h];
+            }
+            CHK(upload(e, &w.bias_exp, be.data(), be.size()));
+            w.mask = nullptr;
+            if ((b % 2 == 1) && R > kWin) {
+                const std::string km = p + "attn_mask";
+                CHK(expect_shape(get(e, km), km, {nW, 64, 64}));
+                CHK(upload(e, &w.mask, get(e, km)->f(), (size_t)nW * 4096));
+            }
+            e->blocks[s].push_back(w);
+        }
+        if (s < 3) {
+            const std::string p = E + "layers." + std::to_string(s) + ".downsample.";
+            CHK(up_vec(e, p + "norm.weight", 4 * C, &e->merge[s].nw));
+            CHK(up_vec(e, p + "norm.bias", 4 * C, &e->merge[s].nb));
+            CHK(pack_key(e, p + "reduction.weight", 2 * C, 4 * C, &e->merge[s].red));
+        }
+    }
+    // ---- tail ----
+    CHK(up_vec(e, E + "norm.weight", kEncOut, &e->fn_w));
+    CHK(up_vec(e, E + "norm.bias", kEncOut, &e->fn_b));
+    {
+        const std::string k = E + "tscam_conv.weight";
+        CHK(expect_shape(get(e, k), k, {kClasses, kEncOut, 2, 3}));
+        // conv weight [o][ch][cf][dt] -> GEMM weight [o][(cf*3+dt)*768 + ch]
+        std::vector<float> wt((size_t)kClasses * 4608);
+        const float* src = get(e, k)->f();
+        for (int o = 0; o < kClasses; ++o)
+            for (int ch = 0; ch < kEncOut; ++ch)
+                for (int cf = 0; cf < 2; ++cf)
+                    for (int dt = 0; dt < 3; ++dt)
+                        wt[(size_t)o * 4608 + (cf * 3 + dt) * 768 + ch] = src[(((size_t)o * kEncOut + ch) * 2 + cf) * 3 + dt];
+        CHK(make_packed(e, wt.data(), nullptr, kClasses, 4608, &e->tscam));
+        CHK(up_vec(e, E + "tscam_conv.bias", kClasses, &e->tscam_b, e->tscam.NP));
+    }
+    CHK(pack_key(e, std::string(C2L) + "weight", kEncOut, kClasses, &e->c2l));
+    CHK(up_vec(e, std::string(C2L) + "bias", kEncOut, &e->c2l_b, e->c2l.NP));
+    CHK(pack_key(e, std::string(PRJ) + "linear1.weight", kProj, kEncOut, &e->lin1));
+    CHK(pack_key(e, std::string(PRJ) + "linear2.weight", kProj, kProj, &e->lin2));
+    CHK(up_vec(e, std::string(PRJ) + "layer_norm.weight", kProj, &e->pln_w));
+    CHK(up_vec(e, std::string(PRJ) + "layer_norm.bias", kProj, &e->pln_b));
+    {
+        std::vector<int32_t> m(32);
+        for (int i = 0; i < 32; ++i) m[i] = i + 1;
+        float* d = nullptr;
+        CHK(upload(e, &d, reinterpret_cast<const float*>(m.data()), 32));
+        e->emb_row_map = reinterpret_cast<int32_t*>(d);
+    }
+    // ---- LM ----
+    const std::string L = LMK;
+    const int H = e->cfg.hidden_size, V = e->cfg.vocab_size, I = e->cfg.intermediate_size;
+    {
+        const std::string k = L + "model.embed_tokens.weight";
+        CHK(expect_shape(get(e, k), k, {V, H}));
+        CHK(upload(e, &e->embed, get(e, k)->f(), (size_t)V * H));
+        CHK(make_packed(e, get(e, k)->f(), nullptr, V, H, &e->lm_head));
+    }
+    for (int l = 0; l < e->cfg.num_layers; ++l) {
+        const std::string p = L + "model.layers." + std::to_string(l) + ".";
+        LMLayerW w{};
+        const HostTensor *q = get(e, p + "self_attn.q_proj.weight"), *k = get(e, p + "self_attn.k_proj.weight"),
+                         *v = get(e, p + "self_attn.v_proj.weight");
+        CHK(expect_shape(q, p + "self_attn.q_proj.weight", {576, H}));
+        CHK(expect_shape(k, p + "self_attn.k_proj.weight", {192, H}));
+        CHK(expect_shape(v, p + "self_attn.v_proj.weight", {192, H}));
+        std::vector<float> qkv((size_t)960 * H);
+        memcpy(qkv.data(), q->f(), (size_t)576 * H * 4);
+        memcpy(qkv.data() + (size_t)576 * H, k->f(), (size_t)192 * H * 4);
+        memcpy(qkv.data() + (size_t)768 * H, v->f(), (size_t)192 * H * 4);
+        CHK(make_packed(e, qkv.data(), nullptr, 960, H, &w.qkv));
+        CHK(pack_key(e, p + "self_attn.o_proj.weight", H, 576, &w.o));
+        const HostTensor *g = get(e, p + "mlp.gate_proj.weight"), *u = get(e, p + "mlp.up_proj.weight");
+        CHK(expect_shape(g, p + "mlp.gate_proj.weight", {I, H}));
+        CHK(expect_shape(u, p + "mlp.up_proj.weight", {I, H}));
+        CHK(make_packed(e, g->f(), u->f(), I, H, &w.gateup));
+        CHK(pack_key(e, p + "mlp.down_proj.weight", H, I, &w.down));
+        CHK(up_vec(e, p + "input_layernorm.weight", H, &w.in_ln));
+        CHK(up_vec(e, p + "post_attention_layernorm.weight", H, &w.post_ln));
+        e->layers.push_back(w);
+    }
+    CHK(up_vec(e, L + "model.norm.weight", H, &e->final_norm));
+    // ---- RoPE tables [max_pos][32]: supplied by the host wrapper (computed the HF way with torch) or built here ----
+    {
+        const int P = e->cfg.max_positions;
+        const HostTensor *tc = get(e, "mellow.rope_cos"), *ts = get(e, "mellow.rope_sin");
+        std::vector<float> c((size_t)P * 32), s((size_t)P * 32);
+        if (tc && ts && tc->numel() == (int64_t)P * 32 && ts->numel() == (int64_t)P * 32) {
+            memcpy(c.data(), tc->f(), c.size() * 4);
+            memcpy(s.data(), ts->f(), s.size() * 4);
+        } else {
+            for (int i = 0; i < 32; ++i) {
+                const float inv = 1.0f / powf(e->cfg.rope_theta, (float)(2 * i) / 64.0f);
+                for (int p = 0; p < P; ++p) {
+                    const float a = inv * (float)p;
+                    c[(size_t)p * 32 + i] = cosf(a);
+                    s[(size_t)p * 32 + i] = sinf(a);
+                }
+            }
+        }
+        CHK(upload(e, &e->rope_cos, c.data(), c.size()));
+        CHK(upload(e, &e->rope_sin, s.data(), s.size()));
+    }
+    // decode state words
+    HIPCHK(hipMalloc(&e->d_tokens, 4096 * sizeof(int32_t)));
+    HIPCHK(hipMemset(e->d_tokens, 0, 4096 * sizeof(int32_t)));
+    e->d_step = e->d_tokens + 1024;
+    e->d_pos = e->d_tokens + 1025;
+    e->d_nseen = e->d_tokens + 1026;
+    e->d_seen = e->d_tokens + 2048;
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+// ---- GEMM wrappers -------------------------------------------------------------------------------------------------------
+static int run_gemm(mellow_engine* e, const GemmArgs& a) {
+    ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+    launch_gemm(a, e->stream);
+    return 0;
+}
+static GemmArgs lin(const float* A, int64_t lda, int M, const Packed& w, float* C, int64_t ldc, const float* bias) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.M = M; g.K = w.KP; g.Wp = w.p; g.Nw = w.Nw; g.N = rup(w.N, 4); g.C = C; g.ldc = ldc; g.bias = bias;
+    return g;
+}
+
+// ---- encoder --------------------------------------------------------------------------------------------------------------
+// wav dev [n][n_samples] -> proj33 [n][33][576] in e->proj33
+static int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, int want_logmel_only, int apply_bn,
+                       float* logmel_out) {
+    if (n <= 0) return fail("n_clips must be positive");
+    if (n_samples % 4 || n_samples < kNfft) return fail("n_samples must be a multiple of 4 and >= 1024");
+    hipStream_t s = e->stream;
+    const int frames = (int)(n_samples / kHop) + 1;
+    const int64_t plen = n_samples + kNfft;
+    const int M = n * frames;
+    CHK(ensure(e, e->wpad, (size_t)n * plen));
+    CHK(ensure(e, e->power, (size_t)M * 544));
+    CHK(ensure(e, e->logmel, (size_t)M * 64));
+    {
+        ProfScope ps(e, PF_MISC, 0, 2.0 * n * plen * 4);
+        launch_reflect_pad(wav, n, n_samples, e->wpad.p, plen, kNfft / 2, s);
+    }
+    {   // A1: STFT power as DFT GEMM on the checkpoint's conv weights (htsat.py:864)
+        GemmArgs g;
+        g.A = e->wpad.p; g.a_mode = A_FRAMES; g.fpc = frames; g.clip_stride = plen; g.hop = kHop;
+        g.M = M; g.K = kNfft; g.Wp = e->dft.p; g.Nw = e->dft.Nw; g.N = 544; g.C = e->power.p; g.ldc = 544; g.epi = EPI_POWER;
+        CHK(run_gemm(e, g));
+    }
+    CHK(tap(e, "power", e->power.p, (int64_t)M * 544));
+    {   // A2+A3: mel projection, 10*log10, bn0 (htsat.py:865-870)
+        GemmArgs g;
+        g.A = e->power.p; g.lda = 544; g.M = M; g.K = 544; g.Wp = e->mel.p; g.Nw = 64; g.N = 64;
+        g.C = want_logmel_only ? logmel_out : e->logmel.p; g.ldc = 64; g.epi = EPI_LOGMEL;
+        g.apply_bn = apply_bn; g.bn_alpha = e->bn_alpha; g.bn_beta = e->bn_beta;
+        CHK(run_gemm(e, g));
+    }
+    if (want_logmel_only) return 0;
+    CHK(tap(e, "logmel_bn", e->logmel.p, (int64_t)M * 64));
+
+    // A4/A4': crops
+    int n_crops = 1, crop_len = frames, crop_hop = 0;
+    if (frames > 1024) {
+        n_crops = 0;
+        for (int p = 0; p < frames - kLongCrop - 1; p += kLongHop) ++n_crops;
+        crop_len = kLongCrop;
+        crop_hop = kLongHop;
+    }
+    const int nv = n * n_crops;
+    const int64_t M0 = (int64_t)nv * 4096;
+    CHK(ensure(e, e->X0, (size_t)M0 * 96));
+    CHK(ensure(e, e->X1, (size_t)M0 * 96));
+    CHK(ensure(e, e->T, (size_t)M0 * 96));
+    CHK(ensure(e, e->QKV, (size_t)M0 * 288));
+    CHK(ensure(e, e->H, (size_t)M0 * 384));
+    {
+        ProfScope ps(e, PF_MISC, 0, (double)M0 * 96 * 4);
+        launch_fold_patch_embed(e->logmel.p, n, frames, n_crops, crop_hop, crop_len, e->pe_w, e->pe_b, e->pe_nw, e->pe_nb,
+                                e->X0.p, s);
+    }
+    CHK(tap(e, "patch", e->X0.p, M0 * 96));
+    float *x = e->X0.p, *x2 = e->X1.p, *t = e->T.p;
+    for (int st = 0; st < 4; ++st) {
+        const int C = 96 << st, R = 64 >> st, N = R * R, nH = kHeads[st];
+        const int nW = R > kWin ? (R / kWin) * (R / kWin) : 1;
+        const int M1 = nv * N;
+        for (int b = 0; b < kDepths[st]; ++b) {
+            const SwinBlockW& w = e->blocks[st][b];
+            const bool shifted = (b % 2 == 1) && R > kWin;
+            const int32_t* map = R > kWin ? e->win_map[st][shifted ? 1 : 0] : nullptr;
+            { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n1w, w.n1b, map, N, s); }
+            CHK(run_gemm(e, lin(t, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b)));
+            {
+                ProfScope ps(e, PF_WINDOW_ATTN, 4.0 * 64 * 64 * 24 * (double)(M1 / 64) * nH, 4.0 * M1 * C * 4);
+                launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s);
+            }
+            {
+                GemmArgs g = lin(t, C, M1, w.proj, x, C, w.proj_b);
+                g.resid = x; g.ldr = C; g.crow_map = map; g.rows_in = N; g.rows_out = N;
+                CHK(run_gemm(e, g));
+            }
+            { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n2w, w.n2b, nullptr, N, s); }
+            {
+                GemmArgs g = lin(t, C, M1, w.fc1, e->H.p, 4 * C, w.fc1_b);
+                g.act = ACT_GELU;
+                CHK(run_gemm(e, g));
+            }
+            {
+                GemmArgs g = lin(e->H.p, 4 * C, M1, w.fc2, x, C, w.fc2_b);
+                g.resid = x; g.ldr = C;
+                CHK(run_gemm(e, g));
+            }
+        }
+        if (st < 3) {
+            { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_merge_layernorm(x, t, nv, R, C, e->merge[st].nw, e->merge[st].nb, s); }
+            CHK(run_gemm(e, lin(t, 4 * C, M1 / 4, e->merge[st].red, x2, 2 * C, nullptr)));
+            float* tmp = x; x = x2; x2 = tmp;
+        }
+        if (e->taps_on) {
+            char nm[16];
+            snprintf(nm, sizeof(nm), "stage%d", st);
+            const int64_t cnt = st < 3 ? (int64_t)nv * (N / 4) * (2 * C) : (int64_t)nv * N * C;
+            CHK(tap(e, nm, x, cnt));
+        }
+    }
+    // ---- tail (htsat.py:742-796, 950-955; mellow.py:48-52) ----
+    CHK(ensure(e, e->ats, (size_t)nv * 32 * 4608));
+    CHK(ensure(e, e->fpx, (size_t)nv * 32 * 544));
+    CHK(ensure(e, e->emb33, (size_t)n * 33 * 768));
+    CHK(ensure(e, e->e1, (size_t)n * 33 * 576));
+    CHK(ensure(e, e->gbuf, (size_t)n * 33 * 576));
+    CHK(ensure(e, e->sbuf, (size_t)n * 33 * 576));
+    CHK(ensure(e, e->proj33, (size_t)n * 33 * 576));
+    { ProfScope ps(e, PF_NORM, 0, 2.0 * nv * 64 * 768 * 4); launch_layernorm(x, t, nv * 64, kEncOut, e->fn_w, e->fn_b, nullptr, 64, s); }
+    float* latent_dst = e->emb33.p;
+    int64_t latent_stride = 33 * 768;
+    if (n_crops > 1) {
+        CHK(ensure(e, e->latv, (size_t)nv * 768));
+        CHK(ensure(e, e->fpxavg, (size_t)n * 32 * 544));
+        latent_dst = e->latv.p;
+        latent_stride = 768;
+    }
+    { ProfScope ps(e, PF_MISC, 0, 7.0 * nv * 64 * 768 * 4); launch_tail_latent_im2col(t, nv, latent_dst, latent_stride, e->ats.p, s); }
+    {
+        GemmArgs g = lin(e->ats.p, 4608, nv * 32, e->tscam, e->fpx.p, 544, e->tscam_b);
+        g.N = 544; g.act = ACT_SIGMOID;
+        CHK(run_gemm(e, g));
+    }
+    const float* fpx = e->fpx.p;
+    if (n_crops > 1) {
+        ProfScope ps(e, PF_MISC, 0, 0);
+        launch_crop_average(e->fpx.p, n, n_crops, 32 * 544, 32 * 544, e->fpxavg.p, 32 * 544, s);
+        launch_crop_average(e->latv.p, n, n_crops, 768, 768, e->emb33.p, 33 * 768, s);
+        fpx = e->fpxavg.p;
+    }
+    CHK(tap(e, "fpx", fpx, (int64_t)n * 32 * 544));
+    {   // c2l on the 32 distinct framewise rows -> embedding rows 1..32 (htsat.py:952-954)
+        GemmArgs g = lin(fpx, 544, n * 32, e->c2l, e->emb33.p, 768, e->c2l_b);
+        g.crow_map = e->emb_row_map; g.rows_in = 32; g.rows_out = 33;
+        CHK(run_gemm(e, g));
+    }
+    CHK(tap(e, "emb33", e->emb33.p, (int64_t)n * 33 * 768));
+    CHK(run_gemm(e, lin(e->emb33.p, 768, n * 33, e->lin1, e->e1.p, 576, nullptr)));
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_gelu(e->e1.p, e->gbuf.p, (int64_t)n * 33 * 576, s); }
+    {
+        GemmArgs g = lin(e->gbuf.p, 576, n * 33, e->lin2, e->sbuf.p, 576, nullptr);
+        g.resid = e->e1.p; g.ldr = 576;
+        CHK(run_gemm(e, g));
+    }
+    { ProfScope ps(e, PF_NORM, 0, 0); launch_layernorm(e->sbuf.p, e->proj33.p, n * 33, 576, e->pln_w, e->pln_b, nullptr, 33, s); }
+    CHK(tap(e, "proj33", e->proj33.p, (int64_t)n * 33 * 576));
+    CHK(tap(e, "latent", e->emb33.p, 768));  // first clip's latent row (row 0 of emb33)
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- LM ----------------------------------------------------------------------------------------------------------------------
+static inline int rb_of(int B) { return (B + 31) / 32; }
+static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
+
+static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
+    if (Tmax > 2048) return fail("prefix + max_len = %d exceeds the 2048-key decode attention limit", Tmax);
+    if (Tmax > e->cfg.max_positions) return fail("prefix + max_len = %d exceeds max_positions %d", Tmax, e->cfg.max_positions);
+    const size_t Mp = (size_t)B * T;
+    CHK(ensure(e, e->lm_x, Mp * 576));
+    CHK(ensure(e, e->lm_xn, Mp * 576));
+    CHK(ensure(e, e->lm_q, Mp * 576));
+    CHK(ensure(e, e->lm_o, Mp * 576));
+    CHK(ensure(e, e->lm_h, Mp * 1536));
+    const int Bp = rb_of(B) * 32;
+    if (e->kv_B != Bp || e->kv_Tmax != Tmax) {
+        e->kv_B = Bp;
+        e->kv_Tmax = Tmax;
+        CHK(ensure(e, e->kcache, kv_layer_floats(e) * e->cfg.num_layers));
+        CHK(ensure(e, e->vcache, kv_layer_floats(e) * e->cfg.num_layers));
+        if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+    }
+    const bool fresh = e->dx.cap < (size_t)Bp * 576;
+    CHK(ensure(e, e->dx, (size_t)Bp * 576));
+    CHK(ensure(e, e->dqkv, (size_t)Bp * 960));
+    CHK(ensure(e, e->dattn, (size_t)Bp * 576));
+    CHK(ensure(e, e->dgu, (size_t)Bp * 3072));
+    CHK(ensure(e, e->dlogits, (size_t)Bp * e->cfg.vocab_size));
+    if (fresh) {
+        // padded batch rows are computed but never read back; keep them finite
+        HIPCHK(hipMemsetAsync(e->dx.p, 0, (size_t)Bp * 576 * 4, e->stream));
+        if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+    }
+    if (Bp > 1024) return fail("batch too large for the decode state block");
+    return 0;
+}
+
+static int run_skinny(mellow_engine* e, const SkinnyArgs& a) {
+    ProfScope ps(e, PF_SKINNY, 2.0 * 32 * a.RB * (double)a.K * a.N, (double)a.K * a.N * 4);
+    launch_skinny(a, e->stream);
+    return 0;
+}
+
+// final norm + lm_head on dx -> dlogits
+static int run_lm_head(mellow_engine* e, int B) {
+    SkinnyArgs a;
+    a.X = e->dx.p; a.ldx = 576; a.K = 576; a.Wp = e->lm_head.p; a.K8p = e->lm_head.KP / 8; a.N = e->cfg.vocab_size;
+    a.Y = e->dlogits.p; a.ldy = e->cfg.vocab_size; a.RB = rb_of(B); a.pro = PRO_RMSNORM; a.norm_w = e->final_norm;
+    a.eps = e->cfg.rms_norm_eps;
+    return run_skinny(e, a);
+}
+
+static int run_prefill(mellow_engine* e, int B, int T) {
+    hipStream_t s = e->stream;
+    const int M = B * T, Tmax = e->kv_Tmax;
+    float *x = e->lm_x.p, *xn = e->lm_xn.p;
+    for (int l = 0; l < e->cfg.num_layers; ++l) {
+        const LMLayerW& w = e->layers[l];
+        float* kc = e->kcache.p + kv_layer_floats(e) * l;
+        float* vc = e->vcache.p + kv_layer_floats(e) * l;
+        { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
+        {
+            GemmArgs g;
+            g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.qkv.p; g.Nw = 960; g.N = 960; g.epi = EPI_QKV_ROPE;
+            g.q_out = e->lm_q.p; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
+            g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
+            CHK(run_gemm(e, g));
+        }
+        {
+            // causal QK^T + PV: 4*64 flops per (query,key) pair per head
+            ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
+            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, B, T, Tmax, s);
+        }
+        {
+            GemmArgs g = lin(e->lm_o.p, 576, M, w.o, x, 576, nullptr);
+            g.resid = x; g.ldr = 576;
+            CHK(run_gemm(e, g));
+        }
+        { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
+        {
+            GemmArgs g;
+            g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.gateup.p; g.Nw = 3072; g.N = 1536; g.C = e->lm_h.p; g.ldc = 1536;
+            g.epi = EPI_SWIGLU;
+            CHK(run_gemm(e, g));
+        }
+        {
+            GemmArgs g = lin(e->lm_h.p, 1536, M, w.down, x, 576, nullptr);
+            g.resid = x; g.ldr = 576;
+            CHK(run_gemm(e, g));
+        }
+    }
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_take_last(x, B, T, 576, e->dx.p, s); }
+    CHK(run_lm_head(e, B));
+    e->cur_B = B;
+    e->cur_pos = T;
+    HIPCHK(hipMemcpyAsync(e->d_pos, &e->cur_pos, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the 30 decode layers + head on dx at position *d_pos (enqueue only; capture-safe)
+static int enqueue_decode_layers(mellow_engine* e, int B) {
+    hipStream_t s = e->stream;
+    const int RB = rb_of(B), Bp = RB * 32;
+    for (int l = 0; l < e->cfg.num_layers; ++l) {
+        const LMLayerW& w = e->layers[l];
+        float* kc = e->kcache.p + kv_layer_floats(e) * l;
+        float* vc = e->vcache.p + kv_layer_floats(e) * l;
+        SkinnyArgs a;
+        a.X = e->dx.p; a.ldx = 576; a.K = 576; a.Wp = w.qkv.p; a.K8p = w.qkv.KP / 8; a.N = 960; a.Y = e->dqkv.p; a.ldy = 960;
+        a.RB = RB; a.pro = PRO_RMSNORM; a.norm_w = w.in_ln; a.eps = e->cfg.rms_norm_eps;
+        CHK(run_skinny(e, a));
+        {
+            ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1),
+                         2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
+            launch_decode_attention(e->dqkv.p, kc, vc, e->rope_cos, e->rope_sin, e->d_pos, e->dattn.p, Bp, e->kv_Tmax, s);
+        }
+        SkinnyArgs o;
+        o.X = e->dattn.p; o.ldx = 576; o.K = 576; o.Wp = w.o.p; o.K8p = w.o.KP / 8; o.N = 576; o.Y = e->dx.p; o.ldy = 576;
+        o.RB = RB; o.epi = SK_RESID;
+        CHK(run_skinny(e, o));
+        SkinnyArgs gu;
+        gu.X = e->dx.p; gu.ldx = 576; gu.K = 576; gu.Wp = w.gateup.p; gu.K8p = w.gateup.KP / 8; gu.N = 3072; gu.Y = e->dgu.p;
+        gu.ldy = 3072; gu.RB = RB; gu.pro = PRO_RMSNORM; gu.norm_w = w.post_ln; gu.eps = e->cfg.rms_norm_eps;
+        CHK(run_skinny(e, gu));
+        SkinnyArgs d;
+        d.X = e->dgu.p; d.ldx = 3072; d.K = 1536; d.Wp = w.down.p; d.K8p = w.down.KP / 8; d.N = 576; d.Y = e->dx.p; d.ldy = 576;
+        d.RB = RB; d.pro = PRO_SWIGLU; d.epi = SK_RESID;
+        CHK(run_skinny(e, d));
+    }
+    CHK(run_lm_head(e, B));
+    return 0;
+}
+
+extern "C" {
+
+int mellow_debug_enable_taps(mellow_engine_t* e, int on) {
+    if (!e) return fail("null engine");
+    e->taps_on = on != 0;
+    return 0;
+}
+int mellow_debug_tap(mellow_engine_t* e, const char* name, float* out, int64_t capacity, int64_t* numel) {
+    if (!e || !name) return fail("null argument");
+    auto it = e->tap_numel.find(name);
+    if (it == e->tap_numel.end()) return fail("no such tap recorded: %s", name);
+    if (numel) *numel = it->second;
+    if (out) {
+        if (capacity < it->second) return fail("tap buffer too small");
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemcpyAsync(out, e->taps[name].p, it->second * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+int mellow_logmel(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_samples, int apply_bn, float* out) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!wav || !out) return fail("null argument");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(run_encoder(e, wav, n_clips, n_samples, 1, apply_bn, out));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int mellow_encode(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_samples, float* out) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!wav || !out) return fail("null argument");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(run_encoder(e, wav, n_clips, n_samples, 0, 1, nullptr));
+    launch_downsample33(e->proj33.p, n_clips, out, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// audio1|audio2 are separate caller buffers: stage them into one [2B][n] batch so the encoder runs ONE pass
+// of 2B clips (the reference runs two passes of B, mellow.py:105-106)
+static int encode_pair_to_prefix(mellow_engine* e, const float* a1, const float* a2, int64_t n_samples, const int32_t* ids,
+                                 int B, float* prefix_out) {
+    mellow_engine::Buf& cat = e->wavcat;
+    CHK(ensure(e, cat, (size_t)2 * B * n_samples));
+    HIPCHK(hipMemcpyAsync(cat.p, a1, (size_t)B * n_samples * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(cat.p + (size_t)B * n_samples, a2, (size_t)B * n_samples * 4, hipMemcpyDeviceToDevice, e->stream));
+    CHK(run_encoder(e, cat.p, 2 * B, n_samples, 0, 1, nullptr));
+    { ProfScope ps(e, PF_MISC, 0, 0);
+      launch_prefix_assemble(e->proj33.p, e->embed, ids, B, e->cfg.text_len, e->cfg.sep_token_id, prefix_out, e->stream); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mellow_prefix(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples, const int32_t* input_ids,
+                  int B, float* out) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!audio1 || !audio2 || !input_ids || !out) return fail("null argument");
+    if (B <= 0) return fail("B must be positive");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, out));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int reserve, float* logits) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!prefix || B <= 0 || T <= 0 || reserve < 0) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(ensure_lm(e, B, T, T + reserve + 1));
+    HIPCHK(hipMemcpyAsync(e->lm_x.p, prefix, (size_t)B * T * 576 * 4, hipMemcpyDeviceToDevice, e->stream));
+    CHK(run_prefill(e, B, T));
+    if (logits)
+        HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* logits) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!token_ids) return fail("null argument");
+    if (e->cur_B <= 0) return fail("decode step without a prefill");
+    if (e->cur_pos + 1 > e->kv_Tmax) return fail("KV pages exhausted (reserve too small)");
+    HIPCHK(hipSetDevice(e->device));
+    const int B = e->cur_B;
+    launch_gather_rows(e->embed, 576, token_ids, B, 576, e->dx.p, 576, e->stream);
+    CHK(enqueue_decode_layers(e, B));
+    e->cur_pos += 1;
+    HIPCHK(hipMemcpyAsync(e->d_pos, &e->cur_pos, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    if (logits)
+        HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* tokens) {
+    if (!e || !logits || !tokens || B <= 0) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    launch_argmax(logits, B, e->cfg.vocab_size, e->cfg.vocab_size, tokens, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// one decode iteration: record + embed the current tokens, run the layers, pick the next tokens, advance pos
+static int enqueue_step(mellow_engine* e, int B, int32_t* out_tokens, int max_len, int stop_id) {
+    hipStream_t s = e->stream;
+    launch_embed_and_record(e->embed, e->d_tokens, B, 576, e->dx.p, out_tokens, max_len, e->d_step, stop_id, e->d_seen,
+                            e->d_nseen, s);
+    CHK(enqueue_decode_layers(e, B));
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_argmax(e->dlogits.p, B, e->cfg.vocab_size, e->cfg.vocab_size, e->d_tokens, s); }
+    launch_advance(e->d_pos, s);
+    return 0;
+}
+
+extern "C" {
+
+int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
+                    const int32_t* input_ids, int B, int max_len, float top_p, float temperature, int stop_id,
+                    int ignore_stop, int32_t* out_tokens, int32_t* out_len, int32_t* out_steps, float* first_token_ms) {
+    (void)top_p;
+    (void)temperature;  // the reference's top-p/temperature path never changes the arg-max (wrapper.py:219-232)
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!audio1 || !audio2 || !input_ids || !out_tokens) return fail("null argument");
+    if (B <= 0 || max_len <= 0) return fail("B and max_len must be positive");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const int T = e->cfg.prefix_len;
+    CHK(ensure_lm(e, B, T, T + max_len));
+    HIPCHK(hipEventRecord(e->ev_phase[0], s));
+    CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
+    HIPCHK(hipEventRecord(e->ev_phase[1], s));
+    CHK(run_prefill(e, B, T));
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_argmax(e->dlogits.p, B, e->cfg.vocab_size, e->cfg.vocab_size, e->d_tokens, s); }
+    HIPCHK(hipEventRecord(e->ev_phase[2], s));
+    // loop state
+    HIPCHK(hipMemsetAsync(e->d_step, 0, sizeof(int32_t), s));
+    HIPCHK(hipMemsetAsync(e->d_nseen, 0, sizeof(int32_t), s));
+    HIPCHK(hipMemsetAsync(e->d_seen, 0, 1024 * sizeof(int32_t), s));
+
+    const bool graph = e->use_graph && !e->prof_on;
+    if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tokens != out_tokens ||
+                  e->graph_max_len != max_len || e->graph_stop != stop_id)) {
+        if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+        hipGraph_t gr = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_step(e, B, out_tokens, max_len, stop_id);
+        hipError_t ce = hipStreamEndCapture(s, &gr);
+        if (rc) return rc;
+        if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        HIPCHK(hipGraphInstantiate(&e->step_exec, gr, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(gr));
+        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tokens = out_tokens; e->graph_max_len = max_len;
+        e->graph_stop = stop_id;
+    }
+    int steps_done = 0;
+    for (int i = 0; i < max_len; ++i) {
+        if (i == max_len - 1) {
+            // last token: record only
+            launch_embed_and_record(e->embed, e->d_tokens, B, 576, nullptr, out_tokens, max_len, e->d_step, stop_id,
+                                    e->d_seen, e->d_nseen, s);
+            steps_done = i + 1;
+            break;
+        }
+        if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
+        else CHK(enqueue_step(e, B, out_tokens, max_len, stop_id));
+        e->cur_pos += 1;
+        steps_done = i + 1;
+        if (!ignore_stop && (i % 8) == 7) {
+            int32_t seen = 0;
+            HIPCHK(hipMemcpyAsync(&seen, e->d_nseen, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (seen >= B) break;
+        }
+    }
+    HIPCHK(hipEventRecord(e->ev_phase[3], s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&e->phase_ms[i], e->ev_phase[i], e->ev_phase[i + 1]));
+    if (first_token_ms) *first_token_ms = e->phase_ms[0] + e->phase_ms[1];
+    // host-side length bookkeeping (reference wrapper.py:247-254)
+    std::vector<int32_t> toks((size_t)B * max_len);
+    HIPCHK(hipMemcpy(toks.data(), out_tokens, toks.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int ref_steps = steps_done;
+    if (!ignore_stop) {
+        // the reference stops after the first step at which every row has produced stop_id at least once
+        std::vector<char> seen(B, 0);
+        int nseen = 0;
+        for (int st = 0; st < steps_done; ++st) {
+            for (int b = 0; b < B; ++b)
+                if (!seen[b] && toks[(size_t)b * max_len + st] == stop_id) { seen[b] = 1; ++nseen; }
+            if (nseen == B) { ref_steps = st + 1; break; }
+        }
+    }
+    if (out_steps) *out_steps = ref_steps;
+    if (out_len)
+        for (int b = 0; b < B; ++b) {
+            int n = ref_steps;
+            for (int st = 0; st < ref_steps; ++st)
+                if (toks[(size_t)b * max_len + st] == stop_id) { n = st; break; }
+            out_len[b] = n;
+        }
+    return 0;
+}
+
+int mellow_prof_enable(mellow_engine_t* e, int on) {
+    if (!e) return fail("null engine");
+    e->prof_on = on != 0;
+    return 0;
+}
+int mellow_prof_reset(mellow_engine_t* e) {
+    if (!e) return fail("null engine");
+    hipStreamSynchronize(e->stream);
+    e->prof.clear();
+    e->ev_used = 0;
+    return 0;
+}
+int mellow_prof_get(mellow_engine_t* e, int i, int64_t* launches, double* ms, double* flops, double* bytes) {
+    if (!e || i < 0 || i >= PF_COUNT) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int64_t n = 0;
+    double t = 0, f = 0, by = 0;
+    for (const auto& r : e->prof)
+        if (r.fam == i) {
+            float m = 0.f;
+            HIPCHK(hipEventElapsedTime(&m, r.a, r.b));
+            t += m; f += r.flops; by += r.bytes; ++n;
+        }
+    if (launches) *launches = n;
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    if (bytes) *bytes = by;
+    return 0;
+}
+int mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms, float* decode_ms) {
+    if (!e) return fail("null engine");
+    if (encode_ms) *encode_ms = e->phase_ms[0];
+    if (prefill_ms) *prefill_ms = e->phase_ms[1];
+    if (decode_ms) *decode_ms = e->phase_ms[2];
+    return 0;
+}
+int mellow_set_graph(mellow_engine_t* e, int on) {
+    if (!e) return fail("null engine");
+    e->use_graph = on != 0;
+    return 0;
+}
+
+}  // extern "C"

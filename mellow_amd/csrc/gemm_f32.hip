@@ -1,0 +1,333 @@
+// fp32-in / fp32-accumulate GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), the workhorse of
+// the encoder and of LM prefill.  Replaces every nn.Linear / conv-as-matmul ATen call of the reference
+// hot path: htsat.py:130-136, 304, 330, 496-497, 774, 952;
+// mellow.py:49-50; transformers LlamaAttention / LlamaMLP projections.
+//
+// Design (MI355X-first, not a CUDA tiling):
+//  * exact fp32: gfx950 has no TF32; v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain at the full
+//    157 TFLOP/s fp32 rate, so the "bit-closeness to the fp32 reference" mode costs nothing vs VALU.
+//  * both operands live in LDS in MFMA *fragment order*: one lane-linear float4 per lane feeds four
+//    MFMAs (k-pairs (k0+j, k0+4+j)), so every LDS read is a conflict-free ds_read_b128 and a wave
+//    issues one LDS read per four 64-cycle MFMAs.
+//  * weights are pre-tiled once at load time into that order (P-layout, kernels.h), so the W stream is
+//    a plain contiguous 4 KiB copy per (n-tile, k-tile); activations are staged from row-major global
+//    memory as full 128-byte lines (8 rows x 128 B per wave instruction).
+//  * the MFMA is issued as D[n][m] (weight = A operand, activation = B operand): a lane then owns one
+//    output ROW and four consecutive columns per accumulator quad -> float4 epilogue stores, and the
+//    two halves of a (re,im) / (gate,up) / RoPE pair sit in the same lane.
+//  * 4 waves per workgroup, 64x64 per wave (4 accumulators), block 128x128 or 256x64, BK = 32,
+//    double-buffered LDS with register prefetch (one barrier per k-tile).
+//  * XCD-aware block order: all n-blocks of an m-panel run on one XCD (A panel read once per L2).
+#include "common.h"
+#include "kernels.h"
+
+namespace mellow {
+
+struct GemmDev {
+    GemmArgs a;
+    int gm, gn;
+};
+
+template <int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int MT = BM / 32, NTB = BN / 32;      // 32-row tiles per block
+    constexpr int A_F4 = MT;                        // float4 per thread per k-tile (A)
+    constexpr int W_F4 = NTB;                       // float4 per thread per k-tile (W)
+    constexpr int A_STAGE = BM * 8;                 // float4 per stage
+    constexpr int W_STAGE = BN * 8;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float4* As = smem;                              // [2][A_STAGE]
+    float4* Ws = smem + 2 * A_STAGE;                // [2][W_STAGE]
+
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
+    const int pm = L / p.gn, pn = L % p.gn;
+    const int nt0 = pn * NTB;
+    const int K8 = g.K >> 3;
+    const int KT = g.K >> 5;
+
+    // ---- per-thread load descriptors -------------------------------------------------------------
+    const float* a_ptr[A_F4];
+    int a_lds[A_F4];
+#pragma unroll
+    for (int q = 0; q < A_F4; ++q) {
+        const int idx = q * 256 + tid;
+        const int row = ((idx >> 6) << 3) + (idx & 7);
+        const int chunk = (idx >> 3) & 7;
+        int m = pm * BM + row;
+        m = m < g.M ? m : g.M - 1;
+        int64_t off;
+        if (g.a_mode == A_FRAMES) off = (int64_t)(m / g.fpc) * g.clip_stride + (int64_t)(m % g.fpc) * g.hop;
+        else off = (int64_t)m * g.lda;
+        a_ptr[q] = g.A + off + chunk * 4;
+        a_lds[q] = ((chunk >> 1) * MT + (row >> 5)) * 64 + (row & 31) + 32 * (chunk & 1);
+    }
+    const float4* w_ptr[W_F4];
+    int w_lds[W_F4];
+#pragma unroll
+    for (int q = 0; q < W_F4; ++q) {
+        const int idx = q * 256 + tid;
+        const int ln = idx & 63, k8 = (idx >> 6) & 3, ntl = idx >> 8;
+        w_ptr[q] = reinterpret_cast<const float4*>(g.Wp) + ((int64_t)(nt0 + ntl) * K8 + k8) * 64 + ln;
+        w_lds[q] = (k8 * NTB + ntl) * 64 + ln;
+    }
+
+    f32x16 acc[2][2];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_F4], rw[W_F4];
+#pragma unroll
+    for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q]);
+#pragma unroll
+    for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][0];
+#pragma unroll
+    for (int q = 0; q < A_F4; ++q) As[a_lds[q]] = ra[q];
+#pragma unroll
+    for (int q = 0; q < W_F4; ++q) Ws[w_lds[q]] = rw[q];
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        // prefetch the next k-tile into registers (the last iteration harmlessly re-reads its own tile so the
+        // register arrays stay unconditional and are never demoted to scratch)
+        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q] + ktn * 32);
+#pragma unroll
+        for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][(int64_t)ktn * 4 * 64];
+        const float4* Ac = As + cur * A_STAGE;
+        const float4* Wc = Ws + cur * W_STAGE;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const float4 a0 = Ac[(k8 * MT + 2 * wm) * 64 + lane];
+            const float4 a1 = Ac[(k8 * MT + 2 * wm + 1) * 64 + lane];
+            const float4 w0 = Wc[(k8 * NTB + 2 * wn) * 64 + lane];
+            const float4 w1 = Wc[(k8 * NTB + 2 * wn + 1) * 64 + lane];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a0.z, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a1.z, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a0.z, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a1.z, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a0.w, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a1.w, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a0.w, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a1.w, acc[1][1], 0, 0, 0);
+        }
+        {
+            float4* An = As + (cur ^ 1) * A_STAGE;
+            float4* Wn = Ws + (cur ^ 1) * W_STAGE;
+#pragma unroll
+            for (int q = 0; q < A_F4; ++q) An[a_lds[q]] = ra[q];
+#pragma unroll
+            for (int q = 0; q < W_F4; ++q) Wn[w_lds[q]] = rw[q];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m_local = lane&31 of each m-tile, columns 8g + 4h + (0..3) ----------
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
+        if (m >= g.M) continue;
+        if constexpr (EPI == EPI_LINEAR) {
+            int64_t crow = m;
+            if (g.crow_map) crow = (int64_t)(m / g.rows_in) * g.rows_out + g.crow_map[m % g.rows_in];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = pn * BN + wn * 64 + ni * 32 + 8 * gq + 4 * h;
+                    if (col >= g.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * gq + j];
+                    if (g.bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (g.act == ACT_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                    } else if (g.act == ACT_SIGMOID) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]);
+                    }
+                    if (g.resid) {
+                        const float4 r = *reinterpret_cast<const float4*>(g.resid + crow * g.ldr + col);
+                        v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
+                    }
+                    *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else {
+            // pair epilogues: n-tile 2*wn holds the first half of the pair, 2*wn+1 the second
+            const int P = pn * WN + wn;  // 64-column group index
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int i0 = 8 * gq + 4 * h;  // 0..31 within the pair
+                float x1[4], x2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x1[j] = acc[0][mi][4 * gq + j]; x2[j] = acc[1][mi][4 * gq + j]; }
+                if constexpr (EPI == EPI_POWER) {
+                    // re^2 + im^2 with separate roundings, like torch's real**2 + imag**2
+                    const int col = P * 32 + i0;
+                    if (col >= g.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fmul_rn(x1[j], x1[j]), __fmul_rn(x2[j], x2[j]));
+                    *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (EPI == EPI_SWIGLU) {
+                    const int col = P * 32 + i0;
+                    if (col >= g.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __fmul_rn(siluf_(x1[j]), x2[j]);
+                    *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (EPI == EPI_LOGMEL) {
+                    // not a pair epilogue: both tiles are plain mel columns
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int col = P * 64 + ni * 32 + i0;
+                        if (col >= g.N) continue;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = ni == 0 ? x1[j] : x2[j];
+                            x = fmaxf(x, 1e-10f);
+                            x = __fmul_rn(10.0f, log10f(x));
+                            if (g.apply_bn) x = __fadd_rn(__fmul_rn(x, g.bn_alpha[col + j]), g.bn_beta[col + j]);
+                            v[j] = x;
+                        }
+                        *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else if constexpr (EPI == EPI_QKV_ROPE) {
+                    // P = head slot: [0,q_heads) query heads, then kv_heads key heads, then kv_heads value heads
+                    const int b = m / g.T, t = m % g.T;
+                    if (P < g.q_heads + g.kv_heads) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(g.rope_cos + (int64_t)t * 32 + i0);
+                        const float4 s4 = *reinterpret_cast<const float4*>(g.rope_sin + (int64_t)t * 32 + i0);
+                        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+                        const float sn[4] = {s4.x, s4.y, s4.z, s4.w};
+                        float o1[4], o2[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // q*cos + rotate_half(q)*sin, products rounded separately (HF apply_rotary_pos_emb)
+                            o1[j] = __fadd_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(-x2[j], sn[j]));
+                            o2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
+                        }
+                        float* dst;
+                        if (P < g.q_heads) dst = g.q_out + (int64_t)m * (g.q_heads * 64) + P * 64;
+                        else dst = g.k_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
+                        *reinterpret_cast<float4*>(dst + i0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                        *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                    } else if (P < g.q_heads + 2 * g.kv_heads) {
+                        float* dst = g.v_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads - g.kv_heads)) * g.Tmax + t) * 64;
+                        *reinterpret_cast<float4*>(dst + i0) = make_float4(x1[0], x1[1], x1[2], x1[3]);
+                        *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(x2[0], x2[1], x2[2], x2[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int EPI>
+static void launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    GemmDev d;
+    d.a = a;
+    d.gm = (a.M + BM - 1) / BM;
+    d.gn = (a.Nw + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+}
+
+template <int EPI>
+static void launch_epi(const GemmArgs& a, hipStream_t s) {
+    // pick the block shape that wastes fewer padded columns: 128x128 or 256x64
+    const int w128 = (a.Nw + 127) / 128 * 128, w64 = (a.Nw + 63) / 64 * 64;
+    if (w64 < w128 && a.M >= 256) launch_cfg<4, 1, EPI>(a, s);
+    else launch_cfg<2, 2, EPI>(a, s);
+}
+
+void launch_gemm(const GemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_LINEAR: launch_epi<EPI_LINEAR>(a, s); break;
+        case EPI_POWER: launch_epi<EPI_POWER>(a, s); break;
+        case EPI_LOGMEL: launch_epi<EPI_LOGMEL>(a, s); break;
+        case EPI_SWIGLU: launch_epi<EPI_SWIGLU>(a, s); break;
+        case EPI_QKV_ROPE: launch_epi<EPI_QKV_ROPE>(a, s); break;
+    }
+}
+
+double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.K * (double)a.Nw; }
+
+// ---- weight packing (runs once per tensor at load time) ---------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int N, int K,
+                                   int64_t ldw, float* __restrict__ out, int NP, int KP) {
+    // one thread per packed float4
+    const int64_t total = (int64_t)(NP / 32) * (KP / 8) * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int64_t tile = i >> 6;
+        const int k8 = (int)(tile % (KP / 8));
+        const int nt = (int)(tile / (KP / 8));
+        const int n = nt * 32 + (lane & 31);
+        const int k0 = k8 * 8 + 4 * (lane >> 5);
+        const float* src = nullptr;
+        int row = -1;
+        if (w1 == nullptr) {
+            if (n < N) { src = w0; row = n; }
+        } else {
+            // pairs-interleaved: 64-row group j = n/64; first 32 rows from w0, next 32 from w1
+            const int j = n >> 6, i32 = n & 31, r = j * 32 + i32;
+            if (r < N) { src = (n & 32) ? w1 : w0; row = r; }
+        }
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (src) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < K) v[j] = src[(int64_t)row * ldw + k0 + j];
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+void launch_pack_weight(const float* w, int N, int K, int64_t ldw, float* out, int NP, int KP, hipStream_t s) {
+    const int64_t total = (int64_t)(NP / 32) * (KP / 8) * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, w, (const float*)nullptr, N, K, ldw, out, NP, KP);
+}
+void launch_pack_weight_pairs(const float* w0, const float* w1, int N, int K, int64_t ldw, float* out, int NP, int KP,
+                              hipStream_t s) {
+    const int64_t total = (int64_t)(NP / 32) * (KP / 8) * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, w0, w1, N, K, ldw, out, NP, KP);
+}
+
+}  // namespace mellow

@@ -1,0 +1,129 @@
+// Causal GQA flash attention for LM prefill in exact fp32 on v_mfma_f32_32x32x2_f32 (replaces the
+// eager/sdpa attention inside transformers' LlamaAttention for the 389-token prefix).
+//
+// One workgroup = (example b, kv head g, 32-query tile); its 3 waves are the 3 query heads that share
+// kv head g (GQA 9q/3kv), so each K/V tile is staged in LDS once for three heads.
+//
+// Register-resident softmax without any cross-lane shuffles of P: the score tile is computed
+// TRANSPOSED, S^T = K Q^T (K tile = MFMA A operand, Q = B operand), so a lane owns ONE query column and
+// 16 keys of the tile; the row max / row sum are 16 in-lane ops + one half-wave exchange.  The P^T
+// accumulator registers are then directly the B operand of O^T += V^T P^T: k-step r pairs the keys
+// {(r&3)+8(r>>2), +4} that the two half-waves hold in register r, and the V^T A-operand is read from
+// the row-major V tile in LDS with consecutive lanes on consecutive dims (conflict-free).
+//   MFMAs per 32x32 tile: 32 (QK^T over d=64) + 32 (PV, two 32-dim halves) = 64 x 64 cycles.
+#include "common.h"
+#include "kernels.h"
+
+namespace mellow {
+
+constexpr int PA_KT_STRIDE = 33;   // transposed K tile row stride (floats): conflict-free b32 reads/writes
+
+__global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __restrict__ q,
+                                                                const float* __restrict__ k_cache,
+                                                                const float* __restrict__ v_cache,
+                                                                float* __restrict__ o, int T, int Tmax) {
+    __shared__ __attribute__((aligned(16))) float Kt[64 * PA_KT_STRIDE];   // [d][key]
+    __shared__ __attribute__((aligned(16))) float Vs[32 * 64];             // [key][d]
+    const int qt = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hq = 3 * g + wave;
+    const int h = lane >> 5, ql = lane & 31;
+    const int q0 = qt * 32;
+    const int qi = q0 + ql;                              // this lane's query position
+    const int qc = qi < T ? qi : T - 1;
+    const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+
+    // Q as MFMA B operand: step s holds Q[query][2s + h], pre-scaled by 1/8 (exact)
+    float qreg[32];
+    {
+        const float* qrow = q + ((int64_t)b * T + qc) * 576 + hq * 64 + h;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qreg[s] = qrow[2 * s] * 0.125f;
+    }
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = 0; kt <= qt; ++kt) {
+        const int k0 = kt * 32;
+        __syncthreads();
+        // stage K (transposed) and V (row-major): 512 float4 each, 192 threads
+        for (int i = tid; i < 512; i += 192) {
+            const int key = i >> 4, quad = i & 15;
+            int t = k0 + key;
+            t = t < T ? t : T - 1;
+            const float4 kv = *reinterpret_cast<const float4*>(kpage + (int64_t)t * 64 + quad * 4);
+            Kt[(quad * 4 + 0) * PA_KT_STRIDE + key] = kv.x;
+            Kt[(quad * 4 + 1) * PA_KT_STRIDE + key] = kv.y;
+            Kt[(quad * 4 + 2) * PA_KT_STRIDE + key] = kv.z;
+            Kt[(quad * 4 + 3) * PA_KT_STRIDE + key] = kv.w;
+            const float4 vv = *reinterpret_cast<const float4*>(vpage + (int64_t)t * 64 + quad * 4);
+            *reinterpret_cast<float4*>(Vs + key * 64 + quad * 4) = vv;
+        }
+        __syncthreads();
+
+        // S^T[key][query] = sum_d K[key][d] Q[query][d]
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float a = Kt[(2 * s + h) * PA_KT_STRIDE + ql];
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+        }
+        // lane: query ql, keys k0 + (r&3) + 8(r>>2) + 4h
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key > qi) S[r] = -INFINITY;          // causal mask (only bites on the diagonal tile)
+            tmax = fmaxf(tmax, S[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);      // finite: key k0 <= q0 <= qi is never masked
+        const float alpha = expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+        float rsum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = expf(S[r] - m_new);
+            rsum += p[r];
+        }
+        rsum += __shfl_xor(rsum, 32, 64);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+        // O^T[d][query] += sum_key V[key][d] P^T[key][query]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float a0 = Vs[key * 64 + ql];
+            const float a1 = Vs[key * 64 + 32 + ql];
+            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p[r], O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p[r], O1, 0, 0, 0);
+        }
+    }
+    if (qi < T) {
+        const float inv = 1.0f / l_run;
+        float* orow = o + ((int64_t)b * T + qi) * 576 + hq * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int d = 8 * gq + 4 * h;
+            *reinterpret_cast<float4*>(orow + d) =
+                make_float4(O0[4 * gq] * inv, O0[4 * gq + 1] * inv, O0[4 * gq + 2] * inv, O0[4 * gq + 3] * inv);
+            *reinterpret_cast<float4*>(orow + 32 + d) =
+                make_float4(O1[4 * gq] * inv, O1[4 * gq + 1] * inv, O1[4 * gq + 2] * inv, O1[4 * gq + 3] * inv);
+        }
+    }
+}
+
+void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
+                              int Tmax, hipStream_t s) {
+    const int qtiles = (T + 31) / 32;
+    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(192), 0, s, q, k_cache, v_cache, o, T, Tmax);
+}
+
+}  // namespace mellow

@@ -1,0 +1,310 @@
+"""ctypes binding of libmellow_hip.so (C ABI in include/mellow_hip.h).
+
+This is the only way Python reaches the hot path.  There is NO CPU fallback: if the shared library is
+missing, or no HIP device is visible, constructing an `Engine` raises — the product path never routes
+through oracle/ or eager PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import spec
+from .spec import LMConfig
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmellow_hip.so")
+ABI_VERSION = 1
+
+_F32, _I32, _I64 = 0, 1, 2
+
+
+class MellowConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
+        ("intermediate_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("rms_norm_eps", C.c_float),
+        ("rope_theta", C.c_float), ("max_positions", C.c_int32), ("text_len", C.c_int32),
+        ("prefix_len", C.c_int32), ("sep_token_id", C.c_int32),
+    ]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libmellow_hip.so and declare every symbol of include/mellow_hip.h.  Raises if missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("MELLOW_HIP_LIB") or LIB_PATH
+    if not os.path.exists(p):
+        raise EngineError(
+            f"{p} not found: build it with `python mellow_amd/csrc/build.py` (hipcc, gfx950). "
+            "The Mellow engine has no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, ci, cf, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+    P = C.POINTER
+    sig = {
+        "mellow_abi_version": (ci, []),
+        "mellow_last_error": (C.c_char_p, []),
+        "mellow_device_count": (ci, []),
+        "mellow_engine_create": (ci, [P(MellowConfig), ci, P(vp)]),
+        "mellow_engine_destroy": (None, [vp]),
+        "mellow_engine_load_tensor": (ci, [vp, C.c_char_p, vp, P(i64), ci, ci]),
+        "mellow_engine_finalize": (ci, [vp]),
+        "mellow_engine_num_required": (ci, []),
+        "mellow_engine_required_key": (C.c_char_p, [ci]),
+        "mellow_generate": (ci, [vp, vp, vp, i64, vp, ci, ci, cf, cf, ci, ci, vp, P(C.c_int32), P(C.c_int32), P(cf)]),
+        "mellow_logmel": (ci, [vp, vp, ci, i64, ci, vp]),
+        "mellow_encode": (ci, [vp, vp, ci, i64, vp]),
+        "mellow_prefix": (ci, [vp, vp, vp, i64, vp, ci, vp]),
+        "mellow_lm_prefill": (ci, [vp, vp, ci, ci, ci, vp]),
+        "mellow_lm_decode_step": (ci, [vp, vp, vp]),
+        "mellow_argmax": (ci, [vp, vp, ci, vp]),
+        "mellow_debug_enable_taps": (ci, [vp, ci]),
+        "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
+        "mellow_prof_enable": (ci, [vp, ci]),
+        "mellow_prof_reset": (ci, [vp]),
+        "mellow_prof_num_families": (ci, []),
+        "mellow_prof_family_name": (C.c_char_p, [ci]),
+        "mellow_prof_get": (ci, [vp, ci, P(i64), P(C.c_double), P(C.c_double), P(C.c_double)]),
+        "mellow_last_phase_ms": (ci, [vp, P(cf), P(cf), P(cf)]),
+        "mellow_set_graph": (ci, [vp, ci]),
+        "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
+        "mellow_host_pack_weight": (ci, [P(cf), ci, ci, ci, P(cf), i64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mellow_abi_version() != ABI_VERSION:
+        raise EngineError(f"ABI mismatch: library {lib.mellow_abi_version()}, binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "mellow_abi_version", "mellow_last_error", "mellow_device_count", "mellow_engine_create",
+    "mellow_engine_destroy", "mellow_engine_load_tensor", "mellow_engine_finalize",
+    "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
+    "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
+    "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
+    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms",
+    "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
+)
+
+
+def hf_rope_tables(max_pos: int, head_dim: int, theta: float):
+    """cos/sin [max_pos][head_dim/2] computed exactly the way transformers' LlamaRotaryEmbedding does
+    (fp32 inv_freq, fp32 outer product, fp32 cos/sin) so the engine uses bit-identical tables."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    pos = torch.arange(max_pos, dtype=torch.float32)
+    freqs = (inv_freq[None, :, None].float() @ pos[None, None, :].float()).transpose(1, 2)[0]
+    return freqs.cos().contiguous().numpy(), freqs.sin().contiguous().numpy()
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One engine per device.  Inputs/outputs are torch tensors on that device (plumbing only)."""
+
+    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 1024):
+        self.lib = load_library()
+        if self.lib.mellow_device_count() <= 0:
+            raise EngineError("no HIP device visible: the Mellow engine needs an MI355X (no CPU fallback)")
+        self.lm = lm or LMConfig.load()
+        self.device = int(device)
+        self.tdev = torch.device(f"cuda:{self.device}")
+        cfg = MellowConfig(
+            abi_version=ABI_VERSION, vocab_size=self.lm.vocab_size, hidden_size=self.lm.hidden_size,
+            intermediate_size=self.lm.intermediate_size, num_layers=self.lm.num_hidden_layers,
+            num_heads=self.lm.num_attention_heads, num_kv_heads=self.lm.num_key_value_heads,
+            head_dim=self.lm.head_dim, rms_norm_eps=self.lm.rms_norm_eps, rope_theta=self.lm.rope_theta,
+            max_positions=int(max_positions), text_len=spec.TEXT_LEN, prefix_len=spec.PREFIX_LEN,
+            sep_token_id=0)
+        self.cfg = cfg
+        h = C.c_void_p()
+        self._chk(self.lib.mellow_engine_create(C.byref(cfg), self.device, C.byref(h)))
+        self.h = h
+        self.finalized = False
+
+    # ---- errors ------------------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = self.lib.mellow_last_error().decode("utf-8", "replace")
+            raise EngineError(msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mellow_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Mirror of `model.load_state_dict` (reference wrapper.py:74-82): every tensor goes to the engine
+        under its reference key; a leading 'module.' is stripped by the engine."""
+        for k, v in sd.items():
+            t = v.detach().cpu().contiguous()
+            if t.dtype == torch.float32:
+                dt = _F32
+            elif t.dtype == torch.int64:
+                dt = _I64
+            elif t.dtype == torch.int32:
+                dt = _I32
+            else:
+                t, dt = t.float(), _F32
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            rc = self.lib.mellow_engine_load_tensor(self.h, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), dt)
+            if rc != 0 and strict:
+                self._chk(rc)
+        cos, sin = hf_rope_tables(self.cfg.max_positions, self.lm.head_dim, self.lm.rope_theta)
+        for name, arr in (("mellow.rope_cos", cos), ("mellow.rope_sin", sin)):
+            shape = (C.c_int64 * 2)(*arr.shape)
+            self._chk(self.lib.mellow_engine_load_tensor(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, 2, _F32))
+        self._chk(self.lib.mellow_engine_finalize(self.h))
+        self.finalized = True
+
+    def required_keys(self):
+        n = self.lib.mellow_engine_num_required()
+        return [self.lib.mellow_engine_required_key(i).decode() for i in range(n)]
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def _f32(self, x) -> torch.Tensor:
+        t = torch.as_tensor(x)
+        return t.to(device=self.tdev, dtype=torch.float32).contiguous()
+
+    def _i32(self, x) -> torch.Tensor:
+        t = torch.as_tensor(x)
+        return t.to(device=self.tdev, dtype=torch.int32).contiguous()
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def generate(self, audio1, audio2, input_ids, max_len: int, top_p: float = 0.8, temperature: float = 1.0,
+                 stop_id: int = 0, ignore_stop: bool = False):
+        """-> (tokens int32 [B, steps] on host, lengths [B], steps, first_token_ms)"""
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._i32(input_ids)
+        B, n = a1.shape
+        assert a2.shape == a1.shape and ids.shape == (B, spec.TEXT_LEN), (a1.shape, a2.shape, ids.shape)
+        out = torch.empty((B, max_len), dtype=torch.int32, device=self.tdev)
+        lens = (C.c_int32 * B)()
+        steps = C.c_int32(0)
+        ftm = C.c_float(0.0)
+        self._chk(self.lib.mellow_generate(self.h, _ptr(a1), _ptr(a2), n, _ptr(ids), B, int(max_len), float(top_p),
+                                           float(temperature), int(stop_id), 1 if ignore_stop else 0, _ptr(out),
+                                           lens, C.byref(steps), C.byref(ftm)))
+        toks = out.cpu().numpy()[:, : steps.value]
+        return toks, np.asarray(list(lens), dtype=np.int32), int(steps.value), float(ftm.value)
+
+    # ---- taps ----------------------------------------------------------------------------------------
+    def logmel(self, wav, apply_bn: bool = False) -> torch.Tensor:
+        w = self._f32(wav)
+        n, ns = w.shape
+        out = torch.empty((n, spec.frames_for(ns), spec.MEL_BINS), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_logmel(self.h, _ptr(w), n, ns, 1 if apply_bn else 0, _ptr(out)))
+        return out
+
+    def encode(self, wav) -> torch.Tensor:
+        w = self._f32(wav)
+        n, ns = w.shape
+        out = torch.empty((n, spec.AUDIO_ROWS, spec.D_PROJ), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_encode(self.h, _ptr(w), n, ns, _ptr(out)))
+        return out
+
+    def prefix(self, audio1, audio2, input_ids) -> torch.Tensor:
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._i32(input_ids)
+        B, n = a1.shape
+        out = torch.empty((B, spec.PREFIX_LEN, spec.D_PROJ), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_prefix(self.h, _ptr(a1), _ptr(a2), n, _ptr(ids), B, _ptr(out)))
+        return out
+
+    def lm_prefill(self, prefix, reserve: int = 64) -> torch.Tensor:
+        p = self._f32(prefix)
+        B, T, H = p.shape
+        out = torch.empty((B, self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_lm_prefill(self.h, _ptr(p), B, T, int(reserve), _ptr(out)))
+        return out
+
+    def lm_decode_step(self, token_ids) -> torch.Tensor:
+        t = self._i32(token_ids).reshape(-1)
+        out = torch.empty((t.shape[0], self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_lm_decode_step(self.h, _ptr(t), _ptr(out)))
+        return out
+
+    def argmax(self, logits) -> torch.Tensor:
+        l = self._f32(logits)
+        out = torch.empty((l.shape[0],), dtype=torch.int32, device=self.tdev)
+        self._chk(self.lib.mellow_argmax(self.h, _ptr(l), l.shape[0], _ptr(out)))
+        return out
+
+    def enable_taps(self, on: bool = True):
+        self._chk(self.lib.mellow_debug_enable_taps(self.h, 1 if on else 0))
+
+    def tap(self, name: str) -> torch.Tensor:
+        n = C.c_int64(0)
+        self._chk(self.lib.mellow_debug_tap(self.h, name.encode(), None, 0, C.byref(n)))
+        out = torch.empty((n.value,), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_debug_tap(self.h, name.encode(), _ptr(out), n.value, C.byref(n)))
+        return out
+
+    # ---- measurement -----------------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        self._chk(self.lib.mellow_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._chk(self.lib.mellow_prof_reset(self.h))
+
+    def prof_report(self):
+        out = {}
+        for i in range(self.lib.mellow_prof_num_families()):
+            n, ms, fl, by = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+            self._chk(self.lib.mellow_prof_get(self.h, i, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+            out[self.lib.mellow_prof_family_name(i).decode()] = {
+                "launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    def last_phase_ms(self):
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        self._chk(self.lib.mellow_last_phase_ms(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"encode_ms": a.value, "prefill_ms": b.value, "decode_ms": c.value}
+
+    def set_graph(self, on: bool):
+        self._chk(self.lib.mellow_set_graph(self.h, 1 if on else 0))
+
+
+# ---- host-only helpers (usable without a GPU) ------------------------------------------------------------
+def host_window_map(R: int, shift: int) -> np.ndarray:
+    lib = load_library()
+    out = (C.c_int32 * (R * R))()
+    if lib.mellow_host_window_map(R, shift, out) != 0:
+        raise EngineError(lib.mellow_last_error().decode())
+    return np.asarray(list(out), dtype=np.int32)
+
+
+def host_pack_weight(w: np.ndarray, npad: int = 128) -> np.ndarray:
+    lib = load_library()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    N, K = w.shape
+    NP, KP = (N + npad - 1) // npad * npad, (K + 31) // 32 * 32
+    out = np.empty((NP // 32, KP // 8, 64, 4), dtype=np.float32)
+    rc = lib.mellow_host_pack_weight(w.ctypes.data_as(C.POINTER(C.c_float)), N, K, npad,
+                                     out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+    if rc != 0:
+        raise EngineError(lib.mellow_last_error().decode())
+    return out
