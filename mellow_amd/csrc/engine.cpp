@@ -136,10 +136,11 @@ struct mellow_engine {
     };
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
-    Buf dx, dqkv, dattn, dgu, dlogits;
+    Buf dx, dxn, pq, dattn, po, pg, pd, dlogits, cand;
     int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
     int kv_B = 0, kv_Tmax = 0;                // current page geometry
     int cur_B = 0, cur_pos = 0;               // host mirror of the decode state
+    int32_t h_pos_word = 0;                   // staging for the device position word
 
     // taps
     bool taps_on = false;
@@ -377,7 +378,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
                                   &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dx,
-                                  &e->dqkv, &e->dattn, &e->dgu, &e->dlogits};
+                                  &e->dxn, &e->pq, &e->dattn, &e->po, &e->pg, &e->pd, &e->dlogits, &e->cand};
     for (auto* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : e->taps)
@@ -823,6 +824,7 @@ static int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samp
 
 // ---- LM ----------------------------------------------------------------------------------------------------------------------
 static inline int rb_of(int B) { return (B + 31) / 32; }
+static const int kKcQkv = SK_KC_QKV, kKcO = SK_KC_O, kKcGu = SK_KC_GU, kKcDown = SK_KC_DOWN;  // kernels.h
 static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
 
 static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
@@ -844,10 +846,14 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
     }
     const bool fresh = e->dx.cap < (size_t)Bp * 576;
     CHK(ensure(e, e->dx, (size_t)Bp * 576));
-    CHK(ensure(e, e->dqkv, (size_t)Bp * 960));
+    CHK(ensure(e, e->dxn, (size_t)Bp * 576));
+    CHK(ensure(e, e->pq, (size_t)kKcQkv * Bp * 960));
     CHK(ensure(e, e->dattn, (size_t)Bp * 576));
-    CHK(ensure(e, e->dgu, (size_t)Bp * 3072));
+    CHK(ensure(e, e->po, (size_t)kKcO * Bp * 576));
+    CHK(ensure(e, e->pg, (size_t)kKcGu * Bp * 3072));
+    CHK(ensure(e, e->pd, (size_t)kKcDown * Bp * 576));
     CHK(ensure(e, e->dlogits, (size_t)Bp * e->cfg.vocab_size));
+    CHK(ensure(e, e->cand, (size_t)2 * Bp * (e->cfg.vocab_size / 32)));
     if (fresh) {
         // padded batch rows are computed but never read back; keep them finite
         HIPCHK(hipMemsetAsync(e->dx.p, 0, (size_t)Bp * 576 * 4, e->stream));
@@ -862,17 +868,42 @@ static int run_skinny(mellow_engine* e, const SkinnyArgs& a) {
     launch_skinny(a, e->stream);
     return 0;
 }
-
-// final norm + lm_head on dx -> dlogits
-static int run_lm_head(mellow_engine* e, int B) {
-    SkinnyArgs a;
-    a.X = e->dx.p; a.ldx = 576; a.K = 576; a.Wp = e->lm_head.p; a.K8p = e->lm_head.KP / 8; a.N = e->cfg.vocab_size;
-    a.Y = e->dlogits.p; a.ldy = e->cfg.vocab_size; a.RB = rb_of(B); a.pro = PRO_RMSNORM; a.norm_w = e->final_norm;
-    a.eps = e->cfg.rms_norm_eps;
-    return run_skinny(e, a);
+static int run_finish(mellow_engine* e, const float* P, int kc, const float* norm_w, int B, int32_t* inc_word) {
+    const int Bp = rb_of(B) * 32;
+    ProfScope ps(e, PF_NORM, 0, (double)(kc + 3) * Bp * 576 * 4);
+    launch_rows_finish(e->dx.p, P, kc, (int64_t)Bp * 576, e->dx.p, norm_w, e->cfg.rms_norm_eps, e->dxn.p, Bp, 576, inc_word,
+                       e->stream);
+    return 0;
 }
 
-static int run_prefill(mellow_engine* e, int B, int T) {
+// loop bookkeeping fused into the arg-max kernel (reference wrapper.py:232-249)
+struct RecordArgs {
+    int32_t* out_tokens = nullptr;
+    int max_len = 0;
+    int stop_id = 0;
+    bool embed_next = false;
+};
+
+// final norm + lm_head (+ fused per-tile arg-max candidates) on dx (+ pending down-proj slabs) -> dlogits, d_tokens
+static int run_lm_head(mellow_engine* e, int B, int pending_kc, const RecordArgs* rec) {
+    const int Bp = rb_of(B) * 32, NT = e->cfg.vocab_size / 32;
+    CHK(run_finish(e, e->pd.p, pending_kc, e->final_norm, B, nullptr));
+    SkinnyArgs a;
+    a.X = e->dxn.p; a.ldx = 576; a.K = 576; a.Wp = e->lm_head.p; a.K8p = e->lm_head.KP / 8; a.N = e->cfg.vocab_size;
+    a.Y = e->dlogits.p; a.ldy = e->cfg.vocab_size; a.RB = rb_of(B); a.kc_out = 1; a.slab_rows_out = Bp;
+    a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * NT);
+    CHK(run_skinny(e, a));
+    {
+        ProfScope ps(e, PF_MISC, 0, 0);
+        launch_argmax_cand(a.cand_val, a.cand_idx, B, NT, e->d_tokens, e->embed, 576,
+                           (rec && rec->embed_next) ? e->dx.p : nullptr, rec ? rec->out_tokens : nullptr,
+                           rec ? rec->max_len : 0, e->d_pos, e->cfg.prefix_len, rec ? rec->stop_id : 0, e->d_seen,
+                           e->d_nseen, e->stream);
+    }
+    return 0;
+}
+
+static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
     hipStream_t s = e->stream;
     const int M = B * T, Tmax = e->kv_Tmax;
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
@@ -912,45 +943,52 @@ static int run_prefill(mellow_engine* e, int B, int T) {
         }
     }
     { ProfScope ps(e, PF_MISC, 0, 0); launch_take_last(x, B, T, 576, e->dx.p, s); }
-    CHK(run_lm_head(e, B));
+    // position word = index of the LAST cached token; the first kernel of every decode step advances it, so the
+    // arg-max below records its token at column (*d_pos - prefix_len + 1) = 0
     e->cur_B = B;
     e->cur_pos = T;
-    HIPCHK(hipMemcpyAsync(e->d_pos, &e->cur_pos, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    e->h_pos_word = T - 1;
+    HIPCHK(hipMemcpyAsync(e->d_pos, &e->h_pos_word, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CHK(run_lm_head(e, B, 0, rec));
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-// the 30 decode layers + head on dx at position *d_pos (enqueue only; capture-safe)
-static int enqueue_decode_layers(mellow_engine* e, int B) {
+// the 30 decode layers + head on dx at position *d_pos (enqueue only; capture-safe).
+// Per layer: finish+norm | qkv split-K | attention | o_proj split-K | finish+norm | gate/up split-K | down split-K
+static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec) {
     hipStream_t s = e->stream;
     const int RB = rb_of(B), Bp = RB * 32;
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const LMLayerW& w = e->layers[l];
         float* kc = e->kcache.p + kv_layer_floats(e) * l;
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
+        CHK(run_finish(e, e->pd.p, l == 0 ? 0 : kKcDown, w.in_ln, B, l == 0 ? e->d_pos : nullptr));
         SkinnyArgs a;
-        a.X = e->dx.p; a.ldx = 576; a.K = 576; a.Wp = w.qkv.p; a.K8p = w.qkv.KP / 8; a.N = 960; a.Y = e->dqkv.p; a.ldy = 960;
-        a.RB = RB; a.pro = PRO_RMSNORM; a.norm_w = w.in_ln; a.eps = e->cfg.rms_norm_eps;
+        a.X = e->dxn.p; a.ldx = 576; a.K = 576; a.Wp = w.qkv.p; a.K8p = w.qkv.KP / 8; a.N = 960; a.Y = e->pq.p; a.ldy = 960;
+        a.RB = RB; a.kc_out = kKcQkv; a.slab_rows_out = Bp;
         CHK(run_skinny(e, a));
         {
             ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1),
                          2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
-            launch_decode_attention(e->dqkv.p, kc, vc, e->rope_cos, e->rope_sin, e->d_pos, e->dattn.p, Bp, e->kv_Tmax, s);
+            launch_decode_attention(e->pq.p, kKcQkv, (int64_t)Bp * 960, kc, vc, e->rope_cos, e->rope_sin, e->d_pos,
+                                    e->dattn.p, Bp, e->kv_Tmax, s);
         }
         SkinnyArgs o;
-        o.X = e->dattn.p; o.ldx = 576; o.K = 576; o.Wp = w.o.p; o.K8p = w.o.KP / 8; o.N = 576; o.Y = e->dx.p; o.ldy = 576;
-        o.RB = RB; o.epi = SK_RESID;
+        o.X = e->dattn.p; o.ldx = 576; o.K = 576; o.Wp = w.o.p; o.K8p = w.o.KP / 8; o.N = 576; o.Y = e->po.p; o.ldy = 576;
+        o.RB = RB; o.kc_out = kKcO; o.slab_rows_out = Bp;
         CHK(run_skinny(e, o));
+        CHK(run_finish(e, e->po.p, kKcO, w.post_ln, B, nullptr));
         SkinnyArgs gu;
-        gu.X = e->dx.p; gu.ldx = 576; gu.K = 576; gu.Wp = w.gateup.p; gu.K8p = w.gateup.KP / 8; gu.N = 3072; gu.Y = e->dgu.p;
-        gu.ldy = 3072; gu.RB = RB; gu.pro = PRO_RMSNORM; gu.norm_w = w.post_ln; gu.eps = e->cfg.rms_norm_eps;
+        gu.X = e->dxn.p; gu.ldx = 576; gu.K = 576; gu.Wp = w.gateup.p; gu.K8p = w.gateup.KP / 8; gu.N = 3072; gu.Y = e->pg.p;
+        gu.ldy = 3072; gu.RB = RB; gu.kc_out = kKcGu; gu.slab_rows_out = Bp;
         CHK(run_skinny(e, gu));
         SkinnyArgs d;
-        d.X = e->dgu.p; d.ldx = 3072; d.K = 1536; d.Wp = w.down.p; d.K8p = w.down.KP / 8; d.N = 576; d.Y = e->dx.p; d.ldy = 576;
-        d.RB = RB; d.pro = PRO_SWIGLU; d.epi = SK_RESID;
+        d.X = e->pg.p; d.ldx = 3072; d.K = 1536; d.Wp = w.down.p; d.K8p = w.down.KP / 8; d.N = 576; d.Y = e->pd.p; d.ldy = 576;
+        d.RB = RB; d.pro = PRO_SWIGLU; d.kc_in = kKcGu; d.slab_rows = Bp; d.kc_out = kKcDown; d.slab_rows_out = Bp;
         CHK(run_skinny(e, d));
     }
-    CHK(run_lm_head(e, B));
+    CHK(run_lm_head(e, B, kKcDown, rec));
     return 0;
 }
 
@@ -1027,7 +1065,7 @@ int mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int
     HIPCHK(hipSetDevice(e->device));
     CHK(ensure_lm(e, B, T, T + reserve + 1));
     HIPCHK(hipMemcpyAsync(e->lm_x.p, prefix, (size_t)B * T * 576 * 4, hipMemcpyDeviceToDevice, e->stream));
-    CHK(run_prefill(e, B, T));
+    CHK(run_prefill(e, B, T, nullptr));
     if (logits)
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1042,9 +1080,8 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
     HIPCHK(hipSetDevice(e->device));
     const int B = e->cur_B;
     launch_gather_rows(e->embed, 576, token_ids, B, 576, e->dx.p, 576, e->stream);
-    CHK(enqueue_decode_layers(e, B));
+    CHK(enqueue_decode_layers(e, B, nullptr));   // its first kernel advances the device position word
     e->cur_pos += 1;
-    HIPCHK(hipMemcpyAsync(e->d_pos, &e->cur_pos, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     if (logits)
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
@@ -1063,17 +1100,6 @@ int mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* token
 
 }  // extern "C"
 
-// one decode iteration: record + embed the current tokens, run the layers, pick the next tokens, advance pos
-static int enqueue_step(mellow_engine* e, int B, int32_t* out_tokens, int max_len, int stop_id) {
-    hipStream_t s = e->stream;
-    launch_embed_and_record(e->embed, e->d_tokens, B, 576, e->dx.p, out_tokens, max_len, e->d_step, stop_id, e->d_seen,
-                            e->d_nseen, s);
-    CHK(enqueue_decode_layers(e, B));
-    { ProfScope ps(e, PF_MISC, 0, 0); launch_argmax(e->dlogits.p, B, e->cfg.vocab_size, e->cfg.vocab_size, e->d_tokens, s); }
-    launch_advance(e->d_pos, s);
-    return 0;
-}
-
 extern "C" {
 
 int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
@@ -1089,23 +1115,25 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     const int T = e->cfg.prefix_len;
     CHK(ensure_lm(e, B, T, T + max_len));
     HIPCHK(hipEventRecord(e->ev_phase[0], s));
-    CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
-    HIPCHK(hipEventRecord(e->ev_phase[1], s));
-    CHK(run_prefill(e, B, T));
-    { ProfScope ps(e, PF_MISC, 0, 0); launch_argmax(e->dlogits.p, B, e->cfg.vocab_size, e->cfg.vocab_size, e->d_tokens, s); }
-    HIPCHK(hipEventRecord(e->ev_phase[2], s));
-    // loop state
-    HIPCHK(hipMemsetAsync(e->d_step, 0, sizeof(int32_t), s));
+    // loop state (the prefill's arg-max already records token 0)
     HIPCHK(hipMemsetAsync(e->d_nseen, 0, sizeof(int32_t), s));
     HIPCHK(hipMemsetAsync(e->d_seen, 0, 1024 * sizeof(int32_t), s));
+    CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
+    HIPCHK(hipEventRecord(e->ev_phase[1], s));
+    RecordArgs rec;
+    rec.out_tokens = out_tokens; rec.max_len = max_len; rec.stop_id = stop_id; rec.embed_next = true;
+    CHK(run_prefill(e, B, T, &rec));
+    HIPCHK(hipEventRecord(e->ev_phase[2], s));
 
-    const bool graph = e->use_graph && !e->prof_on;
+    // one decode step = 30 x (finish | qkv | attention | o_proj | finish | gate/up | down) + finish + lm_head +
+    // arg-max/record/embed, captured once per (B, Tmax, out buffer, max_len, stop id) and replayed
+    const bool graph = e->use_graph && !e->prof_on && max_len > 1;
     if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tokens != out_tokens ||
                   e->graph_max_len != max_len || e->graph_stop != stop_id)) {
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
         hipGraph_t gr = nullptr;
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_step(e, B, out_tokens, max_len, stop_id);
+        int rc = enqueue_decode_layers(e, B, &rec);
         hipError_t ce = hipStreamEndCapture(s, &gr);
         if (rc) return rc;
         if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
@@ -1114,17 +1142,10 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tokens = out_tokens; e->graph_max_len = max_len;
         e->graph_stop = stop_id;
     }
-    int steps_done = 0;
-    for (int i = 0; i < max_len; ++i) {
-        if (i == max_len - 1) {
-            // last token: record only
-            launch_embed_and_record(e->embed, e->d_tokens, B, 576, nullptr, out_tokens, max_len, e->d_step, stop_id,
-                                    e->d_seen, e->d_nseen, s);
-            steps_done = i + 1;
-            break;
-        }
+    int steps_done = 1;   // token 0 came from the prefill
+    for (int i = 1; i < max_len; ++i) {
         if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
-        else CHK(enqueue_step(e, B, out_tokens, max_len, stop_id));
+        else CHK(enqueue_decode_layers(e, B, &rec));
         e->cur_pos += 1;
         steps_done = i + 1;
         if (!ignore_stop && (i % 8) == 7) {

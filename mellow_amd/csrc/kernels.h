@@ -62,25 +62,33 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 
-// ---- skinny (decode) GEMM: Y[32*RB][N] = X[32*RB][K] * W^T with optional fused prologue/epilogue ----
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_SWIGLU = 2 };
-enum { SK_STORE = 0, SK_RESID = 1 };
+// ---- skinny (decode) split-K GEMM: P[kc][32*RB][N] = X[32*RB][K-slice kc] * W^T -----------------------------
+enum { PRO_PLAIN = 0, PRO_SWIGLU = 2 };
+// split-K factors of the decode GEMMs (compile-time: slab sums are fully unrolled): K/8 = KC * 4 waves * KPW
+constexpr int SK_KC_QKV = 9, SK_KC_O = 9, SK_KC_GU = 3, SK_KC_DOWN = 16;
 struct SkinnyArgs {
-    const float* X = nullptr;
+    const float* X = nullptr;   // PRO_PLAIN: row-major [rows][ldx]; PRO_SWIGLU: kc_in slabs [kc_in][slab_rows][ldx]
     int64_t ldx = 0;
-    int K = 0;            // logical K (multiple of 8)
+    int K = 0;                  // logical K; K/8 must equal kc_out * 4 * {2,3,6,9,18}
     const float* Wp = nullptr;
-    int K8p = 0;          // packed k8 stride = roundup(K,32)/8
-    int N = 0;            // logical outputs (n-tiles = ceil(N/32))
-    float* Y = nullptr;
+    int K8p = 0;                // packed k8 stride = roundup(K,32)/8
+    int N = 0;                  // logical outputs (n-tiles = ceil(N/32)); multiple of 4
+    float* Y = nullptr;         // partial slabs [kc_out][slab_rows_out][ldy] (may be null when only candidates wanted)
     int64_t ldy = 0;
-    int RB = 1;           // row blocks of 32
+    int RB = 1;                 // row blocks of 32
     int pro = PRO_PLAIN;
-    const float* norm_w = nullptr;
-    float eps = 1e-5f;
-    int epi = SK_STORE;
+    int kc_in = 1;              // PRO_SWIGLU: input slabs to sum
+    int slab_rows = 0;          // rows per input slab
+    int kc_out = 1;             // split-K factor = output slabs
+    int slab_rows_out = 0;      // rows per output slab
+    float* cand_val = nullptr;  // optional fused arg-max candidates [rows][n-tiles] (kc_out must be 1)
+    int32_t* cand_idx = nullptr;
 };
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// x_out[r] = x_in[r] + sum_{s<kc} P[s][r]  (x_out may be null);  xn[r] = norm_w * (x_out[r] * rsqrt(mean^2+eps)) if norm_w
+// inc_word (may be null): a device int32 incremented by one (the decode position word, see engine.cpp)
+void launch_rows_finish(const float* x_in, const float* P, int kc, int64_t slab_stride, float* x_out,
+                        const float* norm_w, float eps, float* xn, int rows, int C, int32_t* inc_word, hipStream_t s);
 
 // ---- front-end ---------------------------------------------------------------------------------------
 void launch_reflect_pad(const float* wav, int n_clips, int64_t n_samples, float* out, int64_t padded_len, int pad,
@@ -124,14 +132,19 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 // causal GQA flash attention over the KV pages written by the QKV epilogue.  q [B*T][576]; o [B*T][576]
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
                               int Tmax, hipStream_t s);
-// one decode step: qkv_raw [32*RB][960] (q|k|v, no RoPE yet) at position *d_pos; applies RoPE, appends
-// K/V to the pages, attends over pos+1 keys.  o [32*RB][576]
-void launch_decode_attention(const float* qkv_raw, float* k_cache, float* v_cache, const float* rope_cos,
-                             const float* rope_sin, const int32_t* d_pos, float* o, int B, int Tmax,
-                             hipStream_t s);
+// one decode step: qkv split-K slabs [kc][rows][960] (q|k|v, no RoPE yet) at position *d_pos; sums the slabs,
+// applies RoPE, appends K/V to the pages, attends over pos+1 keys.  o [32*RB][576]
+void launch_decode_attention(const float* qkv_parts, int kc, int64_t slab_stride, float* k_cache, float* v_cache,
+                             const float* rope_cos, const float* rope_sin, const int32_t* d_pos, float* o, int B,
+                             int Tmax, hipStream_t s);
 
 // ---- sampling / bookkeeping ------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);
+// per-row arg-max over the lm_head's per-tile candidates; optionally (out_tokens != null) records the token at
+// column (*d_pos - T0 + 1) and tracks stop ids; optionally (x != null) gathers embed[token] into x[b]
+void launch_argmax_cand(const float* cand_val, const int32_t* cand_idx, int B, int n_tiles, int32_t* tokens,
+                        const float* embed, int H, float* x, int32_t* out_tokens, int max_len, const int32_t* d_pos,
+                        int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen, hipStream_t s);
 // x[b] = embed[tokens[b]] (x may be null); records tokens[b] into out_tokens[b][*d_step] (out_tokens may be null),
 // updates seen_stop / n_seen, then advances *d_step (when recording)
 void launch_embed_and_record(const float* embed, const int32_t* tokens, int B, int H, float* x, int32_t* out_tokens,

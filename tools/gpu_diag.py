@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))
     t0 = time.time()
     sd = synth.make_state_dict(0)
     eng = Engine(device=0, max_positions=1024)
