@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-pair responses/sec (+ p50 first-token latency) of the Mellow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): v0 167M, batch 32 per GPU,
+2 x 10 s / 32 kHz synthetic clips + 16-token prompt per example, max_len = 64, greedy decode, fixed-length mode
+(stop id ignored so every step runs: deterministic work).  One "step" = one pass of the whole hot path
+(log-mel front-end -> HTSAT encoder -> projection -> prefix -> KV-cached prefill + 63 decode steps) over one batch,
+inputs already resident in HBM.  Weights: seeded synthetic checkpoint with the real state_dict layout
+(the real v0.ckpt cannot be fetched offline).  N > 1: weak scaling, one process per GPU, every rank runs its own
+32 examples and the token ids are all-gathered once per step over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     dominant kernel family (fp32 MFMA GEMM) measured with HIP events on the engine's stream
+  cpu_baseline the oracle (op-for-op CPU port of the reference: no KV cache) timed on a bounded sample (N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic work per response at max_len = 64, prefix 389
+DENSE_GFLOP_PER_RESPONSE = 24.33 + 87.90          # encoder (2 clips) + LM prefill -> MFMA-bound part
+DECODE_GB_PER_RESPONSE_B32 = 2.28                 # fp32 weights/B + KV pages, B = 32 -> HBM-bound part
+
+
+def cpu_baseline(max_len: int, threads: int):
+    """The oracle (CPU port of the reference algorithm, no KV cache) on a bounded sample: one example,
+    encoder + prefix once, then 24 full re-forward decode steps; the remaining steps are extrapolated
+    linearly in sequence length (the reference's per-step cost is ~ proportional to 389+i)."""
+    from mellow_amd import synth
+    from oracle import mellow_oracle as O
+    torch.set_num_threads(threads)
+    sd = synth.make_state_dict(0)
+    a1, a2, ids = synth.make_batch(1)
+    lm = O.LMParams()
+    with torch.no_grad():
+        t0 = time.time()
+        prefix = O.generate_prefix_inference(sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids))
+        t_enc = time.time() - t0
+        n_meas = 24
+        t0 = time.time()
+        O.generate_batch(sd, lm, prefix, n_meas, 0.8, 1.0, -1, last_only=False)
+        t_steps = time.time() - t0
+    T0 = prefix.shape[1]
+    per_tok_step = t_steps / sum(T0 + i for i in range(n_meas))            # seconds per (step x sequence position)
+    t_total = t_enc + per_tok_step * sum(T0 + i for i in range(max_len))
+    return {
+        "value": round(1.0 / t_total, 5), "unit": "responses/s", "cores": threads, "kind": "port",
+        "sample": f"B=1: front-end+encoder+prefix ({t_enc:.2f}s) + {n_meas} no-KV-cache decode steps ({t_steps:.2f}s), "
+                  f"extrapolated linearly in sequence length to max_len={max_len}",
+        "first_token_s": round(t_enc + per_tok_step * T0, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="examples per GPU")
+    ap.add_argument("--max-len", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; running on {n_gpus} GPU(s)", file=sys.stderr)
+
+    from mellow_amd import synth, dist as mdist
+    from mellow_amd.engine import Engine
+    dev = local_rank if world > 1 else 0
+    eng = Engine(device=dev, max_positions=1024)     # raises if libmellow_hip.so or the GPU is missing
+    eng.load_state_dict(synth.make_state_dict(0))
+    B, L = args.batch, args.max_len
+    a1, a2, ids = synth.make_batch(B, first=rank * B)
+    a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
+
+    def step():
+        toks, lens, steps, ftm = eng.generate(a1d, a2d, idsd, max_len=L, top_p=0.8, temperature=1.0, stop_id=0,
+                                              ignore_stop=True)
+        if world > 1:   # the path's single exchange: all-gather of the token ids over RCCL/xGMI
+            mdist.gather_tokens(toks, lens, world * B, L, device=eng.tdev)
+        return ftm
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ftms = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    phases = eng.last_phase_ms()
+
+    # ---- roofline of the dominant kernel family, HIP events on the engine's stream over one more step ----
+    eng.prof_enable(True)
+    eng.prof_reset()
+    step()
+    rep = eng.prof_report()
+    eng.prof_enable(False)
+
+    if rank == 0:
+        total = n_gpus * B * args.steps
+        value = total / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        g = rep["gemm_f32_mfma"]
+        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # whole-path two-phase roofline: t_roof = F_dense/P_mfma + Bytes_decode/BW_hbm
+        t_roof = (DENSE_GFLOP_PER_RESPONSE / (PEAK_F32_MFMA_TFLOPS * 1e3) + DECODE_GB_PER_RESPONSE_B32 / PEAK_HBM_GBS) * B
+        out = {
+            "metric": "audio-pair responses/sec (v0 167M, 2x10s clips, max_len=64, greedy)",
+            "value": round(value, 2), "unit": "responses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"v0 167M, batch {B}/GPU, 2x10s 32kHz synthetic clips + 16-token prompts, max_len={L}, "
+                                   f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",
+                       "global_batch": n_gpus * B, "max_len": L, "parallelism": f"dp{n_gpus}"},
+            "first_token_ms_p50": round(statistics.median(ftms), 2),
+            "phase_ms": {k: round(v, 2) for k, v in phases.items()},
+            "roofline": {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)", "bound": "mfma",
+                         "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
+                         "flops_per_step": g["flops"]},
+            "path_roofline": {"t_roof_ms_per_step": round(t_roof * 1e3, 3),
+                              "frac": round(t_roof * 1e3 / ms_per_step, 4),
+                              "definition": "F_dense/157.3TF + Bytes_decode/8TB/s per response x batch (SURVEY 8d)"},
+            "kernel_families_ms": {k: round(v["ms"], 3) for k, v in rep.items()},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, threads=min(32, os.cpu_count() or 1))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

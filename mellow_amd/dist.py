@@ -1,0 +1,62 @@
+"""Data-parallel sharding of a batch of (audio1, audio2, prompt) examples over the GPUs of one node
+(SURVEY.md §8e): examples are independent, so each rank (one process per GPU) runs the whole hot path on a
+contiguous shard with its own weight replica, and the only communication is ONE all-gather of the generated
+token ids at the end (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
+The payload is tiny (int32 [B_local, max_len] + lengths), so the collective is latency-bound."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of ceil(n/world) examples per rank (the last ranks may be short or empty)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def gather_tokens(tokens: np.ndarray, lengths: np.ndarray, n_total: int, max_len: int, device=None):
+    """All-gather variable-size shards: tokens int32 [n_local, steps_local<=max_len], lengths int32 [n_local].
+    Returns (tokens [n_total, max_len] padded with -1, lengths [n_total]) on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out = np.full((n_total, max_len), -1, dtype=np.int32)
+        out[: tokens.shape[0], : tokens.shape[1]] = tokens
+        return out, np.asarray(lengths, dtype=np.int32)
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    dev = device if device is not None else torch.device("cpu")
+    buf = torch.full((per, max_len + 1), -1, dtype=torch.int32, device=dev)
+    if tokens.shape[0]:
+        buf[: tokens.shape[0], : tokens.shape[1]] = torch.as_tensor(tokens, dtype=torch.int32, device=dev)
+        buf[: tokens.shape[0], max_len] = torch.as_tensor(lengths, dtype=torch.int32, device=dev)
+    out = torch.empty((world * per, max_len + 1), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out, buf) if hasattr(dist, "all_gather_into_tensor") and dev.type != "cpu" else \
+        _all_gather_list(out, buf, world, per)
+    out = out.cpu().numpy()[:n_total]
+    return out[:, :max_len].copy(), out[:, max_len].copy()
+
+
+def _all_gather_list(out: torch.Tensor, buf: torch.Tensor, world: int, per: int):
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    for r, p in enumerate(parts):
+        out[r * per:(r + 1) * per] = p
+
+
+def generate_sharded(generate_fn, audio1, audio2, input_ids, max_len: int, device=None, **kw):
+    """Run `generate_fn(audio1_shard, audio2_shard, ids_shard, max_len=..., **kw) -> (tokens, lengths, steps, ...)`
+    on this rank's shard and gather everything on every rank."""
+    n = len(audio1)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(n, rank, world)
+    if hi > lo:
+        res = generate_fn(audio1[lo:hi], audio2[lo:hi], input_ids[lo:hi], max_len=max_len, **kw)
+        toks, lens = np.asarray(res[0], dtype=np.int32), np.asarray(res[1], dtype=np.int32)
+    else:
+        toks, lens = np.zeros((0, 0), dtype=np.int32), np.zeros((0,), dtype=np.int32)
+    return gather_tokens(toks, lens, n, max_len, device)

@@ -1,0 +1,189 @@
+"""`MellowWrapper` — drop-in for the reference's public API (reference mellow/wrapper.py:25-287,
+re-exported by mellow/__init__.py:1):
+
+    from mellow_amd import MellowWrapper
+    mellow = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True)
+    response = mellow.generate(examples=[[path1, path2, prompt]], max_len=300, top_p=0.8, temperature=1.0)
+
+Host code stays Python (yaml config, checkpoint loading, wav ingest, tokenisation); everything from the
+(B, 320000) waveforms to the generated token ids runs in libmellow_hip.so on the MI355X through the C ABI of
+include/mellow_hip.h.  There is no CPU model path: `use_cuda=False` / `device="cpu"` raise.
+
+What is kept from the reference, quirks included: class attributes `model_repo`/`model_name`;
+`ValueError` for an unknown model; `config/<config>.yaml` key layout; strict `state_dict` load with the
+'module.' retry; prompt right-padded with '!' to 129 ids; sep = token 0; pads attended; multi-channel wav
+flattened not mixed; crop start from the unseeded `random` module; sampling parameters accepted but the result
+is greedy for every value (the reference's top-p filter never removes the arg-max, wrapper.py:220-232); the
+loop stops only when every row has produced the stop id; text is cut at the first '<|endoftext|>'.
+Deviations: `tqdm` progress output is not produced; the B>1/steps==1 mis-shape and B==1/steps==1 crash of
+reference wrapper.py:251-253 are not reproduced (one string per example is always returned).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+from collections import OrderedDict
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import yaml
+
+from . import spec
+from .audio import load_audio_into_tensor
+from .engine import Engine, EngineError
+from .spec import LMConfig
+
+
+def get_model_class(model_type: str):
+    """reference mellow/model/model.py:3-7."""
+    if model_type == "Mellow":
+        return Engine
+    raise NotImplementedError
+
+
+def get_audio_encoder(name: str):
+    """reference mellow/model/audio.py:3-7."""
+    if name == "HTSAT":
+        return "HTSAT"
+    raise Exception("The audio encoder name {} is incorrect or not supported".format(name))
+
+
+class MellowWrapper:
+    """A class for interfacing the Mellow model on MI355X."""
+
+    model_repo = "soham97/mellow"
+    model_name = {"v0": "v0.ckpt", "v0_s": "v0_s.ckpt"}
+
+    def __init__(self, config, model, device, use_cuda=True, *, checkpoint: Optional[str] = None,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: int = 1024):
+        self.supported_versions = self.model_name.keys()
+        if model not in self.supported_versions:
+            raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
+        self.parent_path = Path(os.path.realpath(__file__)).parent
+        self.config_path = os.path.join(self.parent_path, "config", config + ".yaml")
+        self.use_cuda = use_cuda
+        self.device = device
+        self._state_dict = state_dict
+        self.model_path = self._resolve_checkpoint(model, checkpoint) if state_dict is None else "<state_dict>"
+        self._tokenizer_override = tokenizer
+        self._max_positions = max_positions
+        self.model, self.tokenizer, self.args = self.get_model_and_tokenizer(config_path=self.config_path)
+
+    # ---- construction -------------------------------------------------------------------------------------
+    def _resolve_checkpoint(self, model: str, checkpoint: Optional[str]) -> str:
+        if checkpoint is not None:
+            return checkpoint
+        name = self.model_name[model]
+        local = os.environ.get("MELLOW_CKPT_DIR")
+        if local and os.path.exists(os.path.join(local, name)):
+            return os.path.join(local, name)
+        try:  # reference wrapper.py:41-42
+            from huggingface_hub.file_download import hf_hub_download
+            path = hf_hub_download(self.model_repo, name)
+            try:
+                hf_hub_download(self.model_repo, "config.json")   # the reference's download counter
+            except Exception:
+                pass
+            return path
+        except Exception as e:
+            raise FileNotFoundError(
+                f"checkpoint {name} not available offline: pass checkpoint=..., state_dict=..., or set MELLOW_CKPT_DIR ({e})")
+
+    def read_config_as_args(self, config_path):
+        """yaml -> argparse.Namespace whose fields are plain dicts (reference wrapper.py:51-57)."""
+        with open(config_path, "r") as f:
+            yml_config = yaml.load(f, Loader=yaml.FullLoader)
+        return argparse.Namespace(**{k: v for k, v in yml_config.items()})
+
+    def get_model_and_tokenizer(self, config_path):
+        args = self.read_config_as_args(config_path)
+        args.model["decoder"]["prefix_dim"] = args.model["encoder"]["d_proj"]
+        get_model_class(model_type=args.model["model_type"])                  # NotImplementedError on unknown type
+        get_audio_encoder(args.model["encoder"]["audioenc_name"])             # Exception on unknown encoder
+        text_decoder = args.model["decoder"]["text_decoder"]
+        if "smollm2" not in text_decoder.lower():                            # reference decoder.py:30-31
+            raise ValueError(f"text decoder {text_decoder.lower()} not supported")
+        if args.model["decoder"]["prefix_length"] != spec.PREFIX_LEN or args.data["text_tokenization_len"] != spec.TEXT_LEN \
+                or args.model["encoder"]["d_proj"] != spec.D_PROJ or args.data["sampling_rate"] != spec.SAMPLE_RATE:
+            raise ValueError("config does not describe the v0 geometry this engine is built for")
+        if not self.use_cuda or isinstance(self.device, str):
+            raise RuntimeError("MellowWrapper (MI355X engine) has no CPU path: pass use_cuda=True and an integer device")
+        lm = LMConfig.load()
+        engine = Engine(lm=lm, device=int(self.device), max_positions=self._max_positions)
+        sd = self._state_dict
+        if sd is None:
+            sd = torch.load(self.model_path, map_location=torch.device("cpu"))
+        params = 0
+        for k, v in sd.items():
+            kk = k[7:] if k.startswith("module.") else k
+            if kk.endswith(("running_mean", "running_var", "num_batches_tracked", "attn_mask", "relative_position_index")) \
+                    or kk == spec.LM + "lm_head.weight":
+                continue
+            params += math.prod(v.size())
+        engine.load_state_dict(sd, strict=True)       # strict, with the 'module.' retry of wrapper.py:75-82 in the engine
+        tokenizer = self._tokenizer_override
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(text_decoder)
+            tokenizer.add_special_tokens({"pad_token": "!"})
+        model_path = self.model_path.split(os.path.sep)[-1]
+        cfg_name = config_path.split(os.path.sep)[-1]
+        print(f"model {model_path}, {cfg_name}, parameter count: {params}")
+        return engine, tokenizer, args
+
+    # ---- preprocessing ----------------------------------------------------------------------------------------
+    def load_audio_into_tensor(self, audio_path, audio_duration, resample=True):
+        return load_audio_into_tensor(audio_path, audio_duration, self.args.data["sampling_rate"], resample)
+
+    def preprocess_audio(self, audio_files, resample):
+        """-> float32 (B, segment_seconds*sampling_rate) on the engine's device (reference wrapper.py:170-179)."""
+        tensors = [self.load_audio_into_tensor(f, self.args.data["segment_seconds"], resample).reshape(1, -1)
+                   for f in audio_files]
+        return torch.cat(tensors, 0).to(self.model.tdev)
+
+    def preprocess_text(self, prompts):
+        """-> {'input_ids', 'attention_mask'} int64 (B, 129) (reference wrapper.py:181-195; the mask is never used)."""
+        L = self.args.data["text_tokenization_len"]
+        ids, masks = [], []
+        for ttext in prompts:
+            ttext = ttext + " <|endoftext|>" if "gpt" in self.args.model["decoder"]["text_decoder"] else ttext
+            try:
+                tok = self.tokenizer.encode_plus(text=ttext, add_special_tokens=True, truncation=True, max_length=L,
+                                                 padding="max_length", return_tensors="pt")
+            except TypeError:   # old transformers spelling used by the reference
+                tok = self.tokenizer.encode_plus(text=ttext, add_special_tokens=True, truncation=True, max_length=L,
+                                                 pad_to_max_length=True, return_tensors="pt")
+            ids.append(torch.as_tensor(tok["input_ids"]).reshape(-1))
+            masks.append(torch.as_tensor(tok["attention_mask"]).reshape(-1))
+        return {"input_ids": torch.stack(ids, 0), "attention_mask": torch.stack(masks, 0)}
+
+    # ---- generation ---------------------------------------------------------------------------------------------
+    def _generate_batch(self, audio1, audio2, input_ids, entry_length=300, top_p=0.8, temperature=1.0,
+                        stop_token: str = "<|endoftext|>"):
+        stop_token_index = self.tokenizer.encode(stop_token)[0]
+        toks, lens, steps, ftm = self.model.generate(audio1, audio2, input_ids, max_len=entry_length, top_p=top_p,
+                                                     temperature=temperature, stop_id=stop_token_index)
+        self.last_first_token_ms = ftm
+        return [self.tokenizer.decode(x).split("<|endoftext|>")[0] for x in toks]
+
+    def generate(self, examples, max_len, top_p, temperature, stop_token="<|endoftext|>", audio_resample=True):
+        r"""Produces text response for the given audio files and text prompts
+        examples: (list<list>) each example is [audio path 1, audio path 2, text prompt]
+        max_len: (int) maximum length for text generation
+        top_p, temperature: accepted for API parity; decoding is greedy (see module docstring)
+        stop_token: (str) token used to stop text generation
+        audio_resample (bool) True for resampling audio. The model supports only 32 kHz"""
+        audio_paths1, audio_paths2, text_prompts = [], [], []
+        for example in examples:
+            ap1, ap2, tp = example
+            audio_paths1.append(ap1)
+            audio_paths2.append(ap2)
+            text_prompts.append(tp)
+        audio1 = self.preprocess_audio(audio_paths1, resample=audio_resample)
+        audio2 = self.preprocess_audio(audio_paths2, resample=audio_resample)
+        text = self.preprocess_text(text_prompts)
+        return self._generate_batch(audio1, audio2, text["input_ids"], entry_length=max_len, top_p=top_p,
+                                    temperature=temperature, stop_token=stop_token)

@@ -1,0 +1,212 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI (mellow_amd.engine -> libmellow_hip.so), against
+ (a) the golden vectors generated from the imported reference (tests/golden/*.npz), and
+ (b) the CPU oracle on the same seeded inputs,
+plus size-independent properties at the full BASELINE size (B=32, max_len=64).
+
+Tolerances (fp32 path, exact-fp32 MFMA): activations rel 2e-4 of the tensor's max (fp32 summation-order noise of
+deep K=96..4608 reductions); last-position logits atol 3e-3 on logits of std ~24; token ids EXACT (greedy)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mellow_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rel=2e-4, atol=0.0, name=""):
+    got = torch.as_tensor(got).detach().cpu().double()
+    ref = torch.as_tensor(ref).detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name
+    d = float((got - ref).abs().max())
+    lim = atol + rel * float(ref.abs().max())
+    assert d <= lim, f"{name}: max|d| {d:.3e} > {lim:.3e}"
+
+
+@pytest.fixture(scope="module")
+def engine(synth_sd):
+    from mellow_amd.engine import Engine
+    e = Engine(device=0, max_positions=1024)          # raises (does not fall back) without GPU / library
+    e.load_state_dict(synth_sd)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def batch2():
+    return synth.make_batch(2)
+
+
+@pytest.fixture(scope="module")
+def oracle_taps(synth_sd, batch2):
+    from oracle import mellow_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    a1, a2, ids = batch2
+    taps = {}
+    with torch.no_grad():
+        prefix = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids), taps)
+    return prefix, taps
+
+
+def test_native_library_is_loaded(engine):
+    """the product path IS the HIP library: it must be mapped into this process"""
+    maps = open("/proc/self/maps").read()
+    assert "libmellow_hip.so" in maps
+    assert engine.lib.mellow_device_count() >= 1
+
+
+def test_frontend_logmel(engine, batch2, oracle_taps, golden_dir):
+    a1, _, _ = batch2
+    _, t = oracle_taps
+    g = np.load(os.path.join(golden_dir, "enc10.npz"))
+    lm = engine.logmel(a1, apply_bn=False)
+    assert lm.shape == (2, 1001, 64)                       # frame / mel-bin layout: 320000/320 + 1 frames x 64 bins
+    _close(lm, t["logmel"][:, 0], rel=2e-6, atol=5e-5, name="logmel vs oracle")
+    _close(lm, g["logmel"], rel=2e-6, atol=5e-5, name="logmel vs reference golden")
+    lmb = engine.logmel(a1, apply_bn=True)
+    _close(lmb, t["logmel_bn"][:, 0], rel=5e-6, atol=1e-5, name="logmel_bn vs oracle")
+    _close(lmb[:, ::10], g["logmel_bn_sub"], rel=5e-6, atol=1e-5, name="logmel_bn vs golden")
+
+
+def test_encoder_taps(engine, batch2, oracle_taps, golden_dir):
+    a1, _, _ = batch2
+    _, t = oracle_taps
+    g = np.load(os.path.join(golden_dir, "enc10.npz"))
+    engine.enable_taps(True)
+    try:
+        enc = engine.encode(a1)
+        pw = engine.tap("power").reshape(2, 1001, 544)
+        _close(pw[:, :, :513], t["power"][:, 0], rel=2e-6, name="power")
+        assert float(pw[:, :, 513:].abs().max()) == 0.0     # padded bins come from zero weight rows
+        patch = engine.tap("patch").reshape(2, 4096, 96)
+        _close(patch, t["patch"], name="patch")
+        _close(patch[:, g["tok_idx"]], g["patch_sub"], name="patch golden")
+        for s, shp in enumerate([(2, 1024, 192), (2, 256, 384), (2, 64, 768), (2, 64, 768)]):
+            st = engine.tap(f"stage{s}").reshape(shp)
+            _close(st, t[f"stage{s}"], name=f"stage{s}")
+        _close(engine.tap("stage2").reshape(2, 64, 768), g["stage2"], name="stage2 golden")
+        _close(engine.tap("stage3").reshape(2, 64, 768), g["stage3"], name="stage3 golden")
+        fpx = engine.tap("fpx").reshape(2, 32, 544)[:, :, :527]
+        _close(fpx, t["framewise"][:, 0::32], name="framewise (32 distinct rows)")
+        _close(fpx, g["framewise32"], name="framewise golden")
+        emb = engine.tap("emb33").reshape(2, 33, 768)
+        _close(emb[:, 0], t["latent"], name="latent")
+        _close(emb, g["embedding33"], name="embedding33 golden")
+        p33 = engine.tap("proj33").reshape(2, 33, 576)
+        _close(p33, g["projected33"], name="projected33 golden")
+        _close(enc, t["audio1_ds"], name="downsampled audio (129 rows)")
+    finally:
+        engine.enable_taps(False)
+
+
+def test_prefix(engine, batch2, oracle_taps, golden_dir):
+    a1, a2, ids = batch2
+    oprefix, _ = oracle_taps
+    g = np.load(os.path.join(golden_dir, "enc10.npz"))
+    pre = engine.prefix(a1, a2, ids)
+    assert pre.shape == (2, spec.PREFIX_LEN, spec.D_PROJ)
+    _close(pre, oprefix, name="prefix vs oracle")
+    _close(pre, g["prefix"], name="prefix vs reference golden")
+    # layout: sep rows (embedding of id 0) at 129 and 259, text embeddings from 260 (decoder.py:54) are exact copies
+    pre = pre.cpu()
+    ref = torch.from_numpy(g["prefix"])
+    assert torch.equal(pre[:, 129], ref[:, 129]) and torch.equal(pre[:, 259], ref[:, 259])
+    assert torch.equal(pre[:, 260:], ref[:, 260:])
+
+
+def test_lm_prefill_and_decode_logits(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    prefix = torch.from_numpy(e["prefix"])
+    l0 = engine.lm_prefill(prefix, reserve=16)
+    _close(l0, g["logits_step0"], rel=0, atol=3e-3, name="prefill logits")
+    assert engine.argmax(l0).cpu().tolist() == g["tokens"][:, 0].tolist()
+    toks = g["tokens"]
+    for i in range(1, toks.shape[1]):
+        li = engine.lm_decode_step(toks[:, i - 1])
+        _close(li[:, torch.from_numpy(g["sub_vocab"])], g["logits_sub"][i], rel=0, atol=3e-3, name=f"decode step {i}")
+        assert li.argmax(-1).cpu().tolist() == toks[:, i].tolist()
+
+
+def test_generate_tokens_match_reference(engine, batch2, golden_dir):
+    a1, a2, ids = batch2
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    steps = int(g["steps"])
+    toks, lens, n, ftm = engine.generate(a1, a2, ids, max_len=steps, top_p=0.8, temperature=1.0, stop_id=0)
+    assert n == steps and np.array_equal(toks, g["tokens"])
+    assert ftm > 0
+    # sampling parameters never change the arg-max
+    toks2, *_ = engine.generate(a1, a2, ids, max_len=steps, top_p=0.1, temperature=0.3, stop_id=0)
+    assert np.array_equal(toks2, toks)
+    # eager launches == hipGraph replay
+    engine.set_graph(False)
+    toks3, *_ = engine.generate(a1, a2, ids, max_len=steps, stop_id=0)
+    engine.set_graph(True)
+    assert np.array_equal(toks3, toks)
+
+
+def test_stop_token_semantics(engine, batch2, golden_dir):
+    a1, a2, ids = batch2
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    stop = int(g["eos_stop_id"])
+    # B=1: the loop ends right after the stop id; the text is cut before it (wrapper.py:247-254)
+    toks, lens, n, _ = engine.generate(a1[:1], a2[:1], ids[:1], max_len=12, stop_id=stop)
+    assert n == len(g["eos_b1_tokens"]) + 1 and int(lens[0]) == len(g["eos_b1_tokens"])
+    assert toks[0, : lens[0]].tolist() == g["eos_b1_tokens"].tolist() and toks[0, lens[0]] == stop
+    # B=2: row 1 never produces it, so all 12 steps run; row 0 is cut at its stop id
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=12, stop_id=stop)
+    assert n == 12 and lens.tolist() == g["eos_b2_len"].tolist()
+    assert toks[0, : lens[0]].tolist() == g["eos_b2_row0"].tolist()
+    assert toks[1, : lens[1]].tolist() == g["eos_b2_row1"].tolist()
+
+
+def test_long_audio_seven_crop_path(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "long30.npz"))
+    wav = synth.make_clip(int(g["clip_idx"]), int(g["n_samples"]))[None]
+    engine.enable_taps(True)
+    try:
+        enc = engine.encode(wav)
+        _close(enc, g["audio_ds"], name="30 s clip: downsampled projected embedding")
+        _close(engine.tap("fpx").reshape(1, 32, 544)[:, :, :527], g["framewise32"], name="30 s framewise")
+        _close(engine.tap("emb33").reshape(1, 33, 768)[:, 0], g["latent"], name="30 s latent")
+    finally:
+        engine.enable_taps(False)
+
+
+def test_edge_shapes(engine, batch2):
+    a1, a2, ids = batch2
+    # max_len = 1: only the prefill token
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=1, stop_id=0)
+    assert toks.shape == (2, 1) and n == 1
+    # batch rows are independent: a ragged batch (B=3) reproduces the B=2 rows
+    a1b, a2b, idsb = synth.make_batch(3)
+    t3, *_ = engine.generate(a1b, a2b, idsb, max_len=6, stop_id=0, ignore_stop=True)
+    t2, *_ = engine.generate(a1b[:2], a2b[:2], idsb[:2], max_len=6, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t3[:2], t2)
+    with pytest.raises(Exception):
+        engine.generate(a1[:, :1000], a2[:, :1000], ids, max_len=2)     # shorter than one STFT window
+
+
+def test_full_size_properties(engine):
+    """BASELINE configs[1] size (B=32, 2x10 s, max_len=64): properties that need no oracle run."""
+    B, L = 32, 64
+    a1, a2, ids = synth.make_batch(B)
+    a1[5], a2[5], ids[5] = a1[3], a2[3], ids[3]             # duplicate example -> identical rows
+    t, lens, n, ftm = engine.generate(a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
+    assert t.shape == (B, L) and n == L
+    assert (t >= 0).all() and (t < 49152).all()
+    assert np.array_equal(t[5], t[3])
+    t_again, *_ = engine.generate(a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t, t_again)                        # bit-reproducible (no atomics, fixed reduction order)
+    t_short, *_ = engine.generate(a1, a2, ids, max_len=16, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t_short, t[:, :16])                # KV-cache consistency: a longer run extends a shorter one
+    # the first two examples are the golden ones
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gen.npz"))
+    assert np.array_equal(t[:2, : g["tokens"].shape[1]], g["tokens"])
+    # reference stop semantics at full size: stop id := token row 0 produced at step 3
+    stop = int(t[0, 3])
+    ts, lens, n, _ = engine.generate(a1, a2, ids, max_len=L, stop_id=stop)
+    assert int(lens[0]) == 3 and np.array_equal(ts[:, :n], t[:, :n])

@@ -1,0 +1,148 @@
+"""CPU: host logic of the drop-in wrapper — audio ingest (reference wrapper.py:141-168), config / error
+conventions, data-parallel sharding + gather over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mellow_amd import audio, dist as mdist, spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_wav(path, x, sr):
+    from scipy.io import wavfile
+    wavfile.write(path, sr, (np.clip(x, -1, 1) * 32767).astype(np.int16))
+
+
+def test_tile_short_clip(tmp_path):
+    sr = 32000
+    x = np.sin(np.arange(100000) * 0.01).astype(np.float32) * 0.5
+    p = str(tmp_path / "short.wav")
+    _write_wav(p, x, sr)
+    y = audio.load_audio_into_tensor(p, 10, sr)
+    assert y.shape == (320000,) and y.dtype == torch.float32
+    w, _ = audio.load_wav(p)
+    assert torch.equal(y[:100000], w[0]) and torch.equal(y[100000:200000], w[0]) and torch.equal(y[300000:], w[0, :20000])
+
+
+def test_crop_long_clip_with_injected_start(tmp_path):
+    sr = 32000
+    x = (np.arange(400000) % 1000 / 1000.0 - 0.5).astype(np.float32)
+    p = str(tmp_path / "long.wav")
+    _write_wav(p, x, sr)
+    w, _ = audio.load_wav(p)
+    y = audio.load_audio_into_tensor(p, 10, sr, start_index=1234)
+    assert torch.equal(y, w[0, 1234:1234 + 320000])
+    y2 = audio.load_audio_into_tensor(p, 10, sr)              # random start (unseeded, like the reference)
+    assert y2.shape == (320000,)
+
+
+def test_multichannel_is_flattened_not_mixed(tmp_path):
+    from scipy.io import wavfile
+    sr = 32000
+    st = np.stack([np.full(1000, 1000, np.int16), np.full(1000, -2000, np.int16)], 1)
+    p = str(tmp_path / "st.wav")
+    wavfile.write(p, sr, st)
+    y = audio.load_audio_into_tensor(p, 1, sr)
+    assert abs(float(y[0]) - 1000 / 32768) < 1e-7 and abs(float(y[1000]) + 2000 / 32768) < 1e-7   # ch0 then ch1
+
+
+def test_resample_44k_to_32k_length_and_tone():
+    sr0, sr1 = 44100, 32000
+    n = 403604                                                # resource/1.wav of the reference
+    t = np.arange(n) / sr0
+    x = torch.from_numpy(np.sin(2 * np.pi * 440 * t).astype(np.float32))[None]
+    y = audio.resample(x, sr0, sr1)
+    assert y.shape == (1, 292865)                             # ceil(320 * n / 441)
+    ref = np.sin(2 * np.pi * 440 * np.arange(y.shape[1]) / sr1)
+    assert np.abs(y[0, 2000:-2000].numpy() - ref[2000:-2000]).max() < 2e-3
+    assert audio.resample(x, 32000, 32000) is x               # no-op at the model rate
+
+
+def test_reference_fixture_wavs_load():
+    p = "/root/reference/resource/1.wav"
+    if not os.path.exists(p):
+        pytest.skip("reference fixtures are only present in the build container")
+    y = audio.load_audio_into_tensor(p, 10, 32000)
+    assert y.shape == (320000,)
+    w, sr = audio.load_wav(p)
+    assert sr == 44100 and w.shape == (1, 403604)
+    r = audio.resample(w, sr, 32000)
+    assert torch.equal(y[: r.shape[1]], r[0]) and torch.equal(y[r.shape[1]:], r[0, : 320000 - r.shape[1]])
+
+
+def test_wrapper_error_conventions():
+    from mellow_amd import MellowWrapper
+    with pytest.raises(ValueError, match="not supported"):
+        MellowWrapper(config="v0", model="v9", device=0)
+    assert MellowWrapper.model_repo == "soham97/mellow"
+    assert MellowWrapper.model_name == {"v0": "v0.ckpt", "v0_s": "v0_s.ckpt"}
+    from mellow_amd.wrapper import get_audio_encoder, get_model_class
+    with pytest.raises(NotImplementedError):
+        get_model_class("Other")
+    with pytest.raises(Exception, match="incorrect or not supported"):
+        get_audio_encoder("CNN14")
+    # no CPU model path: the product never falls back to eager PyTorch / the oracle
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        MellowWrapper(config="v0", model="v0", device="cpu", use_cuda=False, state_dict={})
+
+
+def test_config_keys_match_reference_layout():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "mellow_amd", "config", "v0.yaml")))
+    assert cfg["data"] == {"sampling_rate": 32000, "segment_seconds": 10, "tokenizer_type": "HuggingFaceTB/SmolLM2-135M",
+                           "text_tokenization_len": 129}
+    assert cfg["model"]["encoder"] == {"audioenc_name": "HTSAT", "transformer_embed_dim": 768, "out_emb": 768, "d_proj": 576}
+    assert cfg["model"]["decoder"] == {"text_decoder": "HuggingFaceTB/SmolLM2-135M", "prefix_length": 389}
+    assert cfg["model"]["model_type"] == "Mellow"
+    lm = spec.LMConfig.load()
+    assert (lm.vocab_size, lm.hidden_size, lm.num_hidden_layers, lm.num_attention_heads, lm.num_key_value_heads) == \
+        (49152, 576, 30, 9, 3)
+
+
+def test_shard_ranges():
+    assert [mdist.shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    assert [mdist.shard_range(5, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
+    assert mdist.shard_range(1, 0, 1) == (0, 1)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mellow_amd import dist as mdist
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, L = 5, 7
+def fake_generate(a1, a2, ids, max_len, **kw):
+    # token = 100*example + step; ragged step counts per shard, like early-stopping shards
+    steps = max_len - rank
+    toks = np.stack([100 * int(i) + np.arange(steps) for i in ids]).astype(np.int32).reshape(len(ids), steps)
+    return toks, np.full(len(ids), steps - 1, np.int32), steps, 0.0
+ex = np.arange(n)
+toks, lens = mdist.generate_sharded(fake_generate, ex, ex, ex, max_len=L)
+assert toks.shape == (n, L) and lens.shape == (n,)
+for i in range(n):
+    owner = [r for r in range(world) if mdist.shard_range(n, r, world)[0] <= i < mdist.shard_range(n, r, world)[1]][0]
+    steps = L - owner
+    assert toks[i, :steps].tolist() == (100 * i + np.arange(steps)).tolist(), (rank, i, toks[i])
+    assert (toks[i, steps:] == -1).all() and lens[i] == steps - 1
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_dp_gather_two_process_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
