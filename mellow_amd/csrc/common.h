@@ -10,15 +10,50 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MELLOW_WAVE 64
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions without LDS traffic ---------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip + s_waitcnt) on gfx950.  A 16-lane all-reduce is
+// instead four DPP-modified VALU ops: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+// (after the two quad steps every quad is uniform, so the mirrors exchange quads / 8-lane halves).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {       // all 16 lanes of a DPP row end with the row's sum
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
     return v;
+}
+// lane ^ 16 inside each 32-lane half (ds_swizzle bit mode: and 0x1F, or 0, xor 0x10)
+__device__ __forceinline__ float swz_xor16(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+// combine the two 32-lane halves: v_permlane32_swap gives every lane its own and the other half's value
+__device__ __forceinline__ float half_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    v += swz_xor16(v);
+    return half_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    v = fmaxf(v, swz_xor16(v));
+    return half_max(v);
 }
 
 // exact-erf GELU (nn.GELU() default, reference htsat.py:121 / mellow.py:50)

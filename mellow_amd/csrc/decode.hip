@@ -1,83 +1,100 @@
-// KV-cached decode step kernels (replace the reference's full re-forward per token, wrapper.py:216-249;
-// SURVEY.md §8a A15/A16).  All HBM-bound: per step they stream the LM weights once (538 MB fp32) and
-// the KV pages of every live example, so the design goal is coalesced 1 KiB-per-wave-instruction
-// streams and as few dependent launches as possible.
+// KV-cached decode step (replaces the reference's full re-forward per generated token, wrapper.py:216-249;
+// SURVEY.md §8a A15/A16).  B = 32 rows per row-block, fp32 everywhere, bit-reproducible (no atomics).
 //
-//  skinny_splitk  P[kc][32][N] = X[32][K-slice] W^T on v_mfma_f32_32x32x2_f32.  The 32 batch rows are exactly
-//                 one MFMA tile; weights come straight from HBM in P-layout (kernels.h) — one lane-linear
-//                 float4 per lane = four MFMAs, no LDS round trip for the streamed operand.
-//  rows_finish    residual add of the split-K slabs + LlamaRMSNorm, one workgroup per batch row.
-//  decode_attn    one workgroup per (example, kv head): RoPE of the new q/k, append K/V to the pages,
-//                 scores for the 3 query heads sharing the KV head from ONE pass over the K page
-//                 (GQA), block softmax in LDS, one pass over the V page.
+// What the profiles of the first two designs showed (profiles/): a decode step moves only
+// 1.2 GB, so it is bound by (a) ~4 us per *dependent* launch (inter-kernel data crosses the XCD L2s via the
+// memory side), (b) the per-CU vector-memory rate (64 B/clk/CU: a workgroup that gathers an activation matrix
+// row by row spends >10k cycles just issuing loads) and (c) serialised round trips (a load behind a branch
+// or a runtime-count loop is a full wait).  Hence this design:
+//
+//   * 5 launches per layer, each spread over 72..288 workgroups:
+//       qkv  (split-K slabs) -> attn (row-parallel, key-split) -> o_proj (complete output) ->
+//       gate/up (complete output) -> down (split-K slabs, consumed by the next layer's qkv/attn)
+//   * every GEMM operand is read with fully coalesced 1 KiB-per-wave loads: weights in P-layout /
+//     P16-layout (kernels.h), activations written by their PRODUCER in MFMA fragment order ("F-layout"):
+//       F32[rb][k/8][lane][4],  lane = (m%32) + 32*((k%8)/4)   (B operand of v_mfma_f32_32x32x2_f32)
+//       F16[rb][k/16][half][lane][4], lane = (m%16) + 16*((k%16)/4), half = (m%32)/16  (…16x16x4_f32)
+//   * all loads of a wave are issued up front in straight-line code (compile-time slab counts, clamped
+//     addresses instead of branches, sched_barrier between the load block and the math);
+//   * the RMSNorm weight is folded into the qkv / gate-up weights at load time and the per-row scale
+//     r = rsqrt(mean(x^2)+eps) is applied by the consumer (attention: q,k,v are linear in r; down: inside
+//     the SwiGLU), so no normalisation launch exists; split-K partial sums ("slabs") are summed by their
+//     consumers in a fixed order.
 #include "common.h"
 #include "kernels.h"
 
 namespace mellow {
 
+// developer instrumentation: when a debug buffer is set, workgroup 0 / thread 0 stamps s_memtime at phase points
+// (compiled in only with -DMELLOW_KDEBUG: the stamps cost ~9 % of a decode step)
+__device__ uint64_t* g_kdbg = nullptr;
+#ifdef MELLOW_KDEBUG
+__device__ __forceinline__ void kstamp(int slot, int idx, bool who) {
+    if (g_kdbg && who) g_kdbg[slot * 8 + idx] = __builtin_readcyclecounter();
+}
+#else
+#define kstamp(slot, idx, who) ((void)0)
+#endif
+void set_kernel_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &p, sizeof(p)); }
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+__device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x.w, acc, 0, 0, 0);
+    return acc;
+}
+// F32-layout float4 index of (row m of row-block rb, columns k..k+3, k % 4 == 0) for an activation with K8 k-tiles
+__device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
+    return ((int64_t)rb * K8 + (k >> 3)) * 64 + m + 32 * ((k >> 2) & 1);
+}
+
 // ----------------------------------------------------------------------------------------------------
-// split-K skinny GEMM.  grid (n-tiles, KC, row-blocks), 4 waves; wave w of k-chunk kc owns KPW
-// consecutive 8-wide k-tiles and issues ALL of its loads (KPW x 1 KiB of weights) before the first
-// MFMA, so a launch has the whole weight matrix in flight at once (a decode layer's matrices are only
-// 1.3-7 MB: latency, not bandwidth, is the enemy).  The 4 waves reduce through LDS and the block writes
-// one deterministic partial slab P[kc][row][n]; slabs are summed by the row-parallel finish kernel
-// (fixed order -> bit-reproducible, no atomics).
+// K1  qkv projection, split-K.  grid (30 n-tiles, DEC_KC_QKV, RB), 4 waves, 2 k-tiles per wave.
+//     X = baseF + sum_{s<KCD} dslabF[s]  (residual stream, un-normalised; norm weight folded into W)
+//     out: pq[kc][row][960] row-major slabs (consumer = attention, row-parallel)
 // ----------------------------------------------------------------------------------------------------
-template <int KPW, int PRO, int KCIN>
-__global__ __launch_bounds__(256) void skinny_splitk_kernel(const SkinnyArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];  // 16 KiB
+template <int KCD>
+__global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
-    const int m = lane & 31, h = lane >> 5;
+    constexpr int KPW = 72 / (DEC_KC_QKV * 4);   // 2
     const int k8_0 = (kc * 4 + wave) * KPW;
-    const float4* wp = reinterpret_cast<const float4*>(a.Wp) + ((int64_t)nt * a.K8p + k8_0) * 64 + lane;
-    float4 w[KPW], x[KPW];
+    // the first kernel of a step advances the position word (nothing of the previous step reads it any more)
+    if (a.inc_pos && tid == 0 && nt == 0 && kc == 0 && rb == 0) *a.d_pos = *a.d_pos + 1;
+    const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
+    kstamp(0, 0, dbg);
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+    const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+    float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) w[i] = wp[i * 64];
-    if (PRO == PRO_SWIGLU) {
-        // X = raw gate/up partial slabs [KCin][rows][ldx] in pair-interleaved 64-column groups:
-        // gate at (k/32)*64 + k%32, up 32 columns later;  x = silu(sum gate) * (sum up)
+    for (int i = 0; i < KPW; ++i) {
+        w[i] = wp[i * 64];
+        x[i] = xb[i * 64];
 #pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int k = (k8_0 + i) * 8 + 4 * h;
-            const int c = ((k >> 5) << 6) + (k & 31);
-            float4 g4[KCIN], u4[KCIN];
-#pragma unroll
-            for (int s = 0; s < KCIN; ++s) {   // compile-time slab count: all loads issue together
-                const float* xr = a.X + ((int64_t)s * a.slab_rows + rb * 32 + m) * a.ldx + c;
-                g4[s] = *reinterpret_cast<const float4*>(xr);
-                u4[s] = *reinterpret_cast<const float4*>(xr + 32);
-            }
-            float4 gt = g4[0], up = u4[0];
-#pragma unroll
-            for (int s = 1; s < KCIN; ++s) {
-                gt.x += g4[s].x; gt.y += g4[s].y; gt.z += g4[s].z; gt.w += g4[s].w;
-                up.x += u4[s].x; up.y += u4[s].y; up.z += u4[s].z; up.w += u4[s].w;
-            }
-            x[i].x = __fmul_rn(siluf_(gt.x), up.x); x[i].y = __fmul_rn(siluf_(gt.y), up.y);
-            x[i].z = __fmul_rn(siluf_(gt.z), up.z); x[i].w = __fmul_rn(siluf_(gt.w), up.w);
-        }
-    } else {
-        const float* xr = a.X + (int64_t)(rb * 32 + m) * a.ldx + k8_0 * 8 + 4 * h;
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) x[i] = *reinterpret_cast<const float4*>(xr + i * 8);
+        for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
     }
-    // keep every load above this point: the whole K-slice of the wave is in flight before the first MFMA
     __builtin_amdgcn_sched_barrier(0);
+    kstamp(0, 1, dbg);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].x, x[i].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].y, x[i].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].z, x[i].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].w, x[i].w, acc, 0, 0, 0);
+        float4 xv = x[i];
+#pragma unroll
+        for (int s = 0; s < KCD; ++s) xv = f4add(xv, sl[i][s]);
+        acc = mfma4(acc, w[i], xv);
     }
+    kstamp(0, 2, dbg && acc[0] == acc[0]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    // thread -> (row mm, column group gq, half hh): 4 consecutive columns n = 8*gq + 4*hh + j  <-  r = 4*gq + j
+    kstamp(0, 3, dbg);
     const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
     float v[4];
 #pragma unroll
@@ -87,11 +104,378 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const SkinnyArgs a) 
                (red[(2 * 16 + r) * 64 + mm + 32 * hh] + red[(3 * 16 + r) * 64 + mm + 32 * hh]);
     }
     const int n = nt * 32 + 8 * gq + 4 * hh;
-    const int row = rb * 32 + mm;
-    if (a.Y && n < a.N)
-        *reinterpret_cast<float4*>(a.Y + ((int64_t)kc * a.slab_rows_out + row) * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-    if (a.cand_val) {
-        // fused arg-max candidates (lm_head, KC == 1): best (value, lowest index) of this 32-column tile per row
+    kstamp(0, 4, dbg);
+    if (n < 960)
+        *reinterpret_cast<float4*>(a.pq + ((int64_t)kc * a.rows + rb * 32 + mm) * 960 + n) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K2  attention (flash decoding).  grid (3 kv heads, rows, DEC_TS key splits), 8 waves.
+//     x_new[b] = base[b] + sum down slabs  ->  r1 (RMS scale);  q,k,v = r1 * sum_kc pq slabs;  RoPE; KV append;
+//     per-wave online softmax over an interleaved set of 4-key groups; partial (m, l, o) per split.
+//     Workgroup (g=0, split=0) also materialises x_new (row-major) for the o_proj residual.
+// ----------------------------------------------------------------------------------------------------
+constexpr int DA_WAVES = 8;
+constexpr int DA_G = 7;          // 4-key groups in flight per wave: one chunk covers 2*8*7*4 = 448 keys
+
+template <int KCD>
+__global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
+                                                                  float* __restrict__ v_cache) {
+    __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
+    __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
+    __shared__ __attribute__((aligned(16))) float ored[DA_WAVES * 3 * 64];
+    __shared__ float mred[DA_WAVES * 3], lred[DA_WAVES * 3];
+    __shared__ float ssq[DA_WAVES];
+    __shared__ float snew_s[3];
+
+    const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Tmax = a.Tmax;
+    float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    const int sub = lane >> 4, quad = lane & 15;   // lane -> (key sub, dim quad): a wave instruction = 4 keys x 64 dims
+
+    // ===== round trip 1 (independent, straight-line): position word, residual row (+slabs), qkv slabs =====
+    const bool dbg = tid == 0 && g == 0 && b == 0 && sp == 0;
+    kstamp(1, 0, dbg);
+    const int pos = *a.d_pos;        // keys 0..pos-1 are cached; the new key is key `pos`
+    // prologue role (branch-free addressing; results masked on use):
+    //   tid <128 : hsel = tid>>5 (0..2 = query head 3g+hsel, 3 = new key), elements i = tid&31 and i+32
+    //   tid <192 : new value element tid-128
+    const int hsel = (tid >> 5) & 3, i = tid & 31;
+    const int col1 = tid < 128 ? (hsel < 3 ? (3 * g + hsel) * 64 : 576 + g * 64) + i : 768 + g * 64 + ((tid - 128) & 63);
+    const int col2 = tid < 128 ? col1 + 32 : col1;
+    const float* prow = a.pq + (int64_t)b * 960;
+    float a1[DEC_KC_QKV], a2[DEC_KC_QKV];
+#pragma unroll
+    for (int s = 0; s < DEC_KC_QKV; ++s) {
+        a1[s] = prow[(int64_t)s * a.rows * 960 + col1];
+        a2[s] = prow[(int64_t)s * a.rows * 960 + col2];
+    }
+    const int xi = tid < 144 ? tid : 0;
+    float4 xv = reinterpret_cast<const float4*>(a.xmidR + (int64_t)b * 576)[xi];
+    float4 xs[KCD > 0 ? KCD : 1];
+#pragma unroll
+    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabR + ((int64_t)s * a.rows + b) * 576)[xi];
+
+    // ===== round trip 2 (needs only pos): RoPE table row, first chunk of K/V =====
+    const float c = a.rope_cos[(int64_t)pos * 32 + i], sn = a.rope_sin[(int64_t)pos * 32 + i];
+    const int ngroups = (pos + 3) >> 2;                       // groups of 4 cached keys
+    const int gper = (ngroups + DEC_TS - 1) / DEC_TS;         // groups per split
+    const int gbeg = sp * gper, gend = min(ngroups, gbeg + gper);
+    float4 k4[DA_G], v4[DA_G];
+#pragma unroll
+    for (int u = 0; u < DA_G; ++u) {
+        const int gi = gbeg + wave + u * DA_WAVES;
+        const int t = gi * 4 + sub;
+        const int tc = (gi < gend && t < pos) ? t : pos - 1;   // pos >= 1 always (a prefix precedes)
+        k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
+        v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kstamp(1, 1, dbg);
+
+    // ---- x_new row, its RMS statistic, materialisation ----
+#pragma unroll
+    for (int s = 0; s < KCD; ++s) xv = f4add(xv, xs[s]);
+    {
+        float ss = tid < 144 ? f4ssq(xv) : 0.f;
+        ss = wave_sum(ss);
+        if (lane == 0) ssq[wave] = ss;
+    }
+    if (g == 0 && sp == 0 && tid < 144) reinterpret_cast<float4*>(a.xnewR + (int64_t)b * 576)[tid] = xv;
+    float x1 = a1[0], x2 = a2[0];
+#pragma unroll
+    for (int s = 1; s < DEC_KC_QKV; ++s) { x1 += a1[s]; x2 += a2[s]; }
+    __syncthreads();
+    kstamp(1, 2, dbg);
+    const float rscale = 1.0f / sqrtf((ssq[0] + ssq[1] + ssq[2]) / 576.0f + a.eps);   // waves 0..2 hold the 144 float4
+    x1 *= rscale; x2 *= rscale;
+    if (tid < 128) {
+        const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sn));
+        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
+        if (hsel < 3) {
+            qs[hsel * 64 + i] = o1 * 0.125f;        // head_dim^-0.5 = 1/8 exactly
+            qs[hsel * 64 + i + 32] = o2 * 0.125f;
+        } else {
+            knew[i] = o1; knew[i + 32] = o2;
+            if (sp == 0) { kpage[(int64_t)pos * 64 + i] = o1; kpage[(int64_t)pos * 64 + i + 32] = o2; }
+        }
+    } else if (tid < 192) {
+        vnew[tid - 128] = x1;
+        if (sp == 0) vpage[(int64_t)pos * 64 + (tid - 128)] = x1;
+    }
+    __syncthreads();
+    kstamp(1, 3, dbg);
+
+    if (wave < 3) {                      // score of the new key (q . k_new, both in LDS), consumed after the last barrier
+        const float sn_ = wave_sum(qs[wave * 64 + lane] * knew[lane]);
+        if (lane == 0) snew_s[wave] = sn_;
+    }
+    float4 q4[3];
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) q4[hh] = *reinterpret_cast<const float4*>(qs + hh * 64 + quad * 4);
+    float m_run[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float l_run[3] = {0.f, 0.f, 0.f};      // per-lane partial (this lane's keys only)
+    float4 acc[3];
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int g0 = gbeg + wave; g0 < gend; g0 += DA_WAVES * DA_G) {
+        if (g0 != gbeg + wave) {           // later chunks (only for contexts beyond 448 keys): reload
+#pragma unroll
+            for (int u = 0; u < DA_G; ++u) {
+                const int gi = g0 + u * DA_WAVES;
+                const int t = gi * 4 + sub;
+                const int tc = (gi < gend && t < pos) ? t : pos - 1;
+                k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
+                v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sc[DA_G][3];
+        float cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int u = 0; u < DA_G; ++u) {
+            const int gi = g0 + u * DA_WAVES;
+            const int t = gi * 4 + sub;
+            const bool ok = gi < gend && t < pos;
+#pragma unroll
+            for (int hh = 0; hh < 3; ++hh) {
+                float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;
+                sv = row16_sum(sv);                  // the 16 dim-quads of a key are one DPP row
+                sv = ok ? sv : -INFINITY;
+                sc[u][hh] = sv;
+                cmax[hh] = fmaxf(cmax[hh], sv);
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+            float cm = cmax[hh];
+            cm = fmaxf(cm, swz_xor16(cm));
+            cm = half_max(cm);
+            const float m_new = fmaxf(m_run[hh], cm);       // finite: key 4*g0 of the chunk is valid
+            const float alpha = expf(m_run[hh] - m_new);    // exp(-inf) = 0 on the first chunk
+            m_run[hh] = m_new;
+            float lsum = 0.f;
+            float4 o = make_float4(acc[hh].x * alpha, acc[hh].y * alpha, acc[hh].z * alpha, acc[hh].w * alpha);
+#pragma unroll
+            for (int u = 0; u < DA_G; ++u) {
+                const float p = expf(sc[u][hh] - m_new);    // masked keys: exp(-inf) = 0
+                lsum += p;
+                o.x += p * v4[u].x; o.y += p * v4[u].y; o.z += p * v4[u].z; o.w += p * v4[u].w;
+            }
+            acc[hh] = o;
+            l_run[hh] = l_run[hh] * alpha + lsum;
+        }
+    }
+    kstamp(1, 4, dbg && l_run[0] == l_run[0]);
+    // reduce the 4 key-subs of the wave; publish (m, l, o) of the wave
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) {
+        float l = l_run[hh];                 // identical across the 16 quads of a sub; sum over the 4 subs
+        l += swz_xor16(l);
+        l = half_sum(l);
+        acc[hh].x += swz_xor16(acc[hh].x); acc[hh].y += swz_xor16(acc[hh].y);
+        acc[hh].z += swz_xor16(acc[hh].z); acc[hh].w += swz_xor16(acc[hh].w);
+        acc[hh].x = half_sum(acc[hh].x); acc[hh].y = half_sum(acc[hh].y);
+        acc[hh].z = half_sum(acc[hh].z); acc[hh].w = half_sum(acc[hh].w);
+        if (sub == 0) *reinterpret_cast<float4*>(ored + (wave * 3 + hh) * 64 + quad * 4) = acc[hh];
+        if (lane == 0) { mred[wave * 3 + hh] = m_run[hh]; lred[wave * 3 + hh] = l; }
+    }
+    __syncthreads();
+    kstamp(1, 5, dbg);
+    if (tid < 48) {
+        // thread -> (head hh, dim quad dq): merged float4 of the 8 waves (+ the new key on the last split)
+        const int hh = tid >> 4, dq = tid & 15;
+        const float snew = snew_s[hh];
+        float M = sp == DEC_TS - 1 ? snew : -INFINITY;   // the last split also owns the new key
+#pragma unroll
+        for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, mred[w * 3 + hh]);
+        float L = 0.f;
+        float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (M > -INFINITY) {                 // an empty split (short context) publishes m = -inf, l = 0, o = 0
+            if (sp == DEC_TS - 1) {
+                const float pn = expf(snew - M);
+                const float4 vn = *reinterpret_cast<const float4*>(vnew + dq * 4);
+                L = pn;
+                O = make_float4(pn * vn.x, pn * vn.y, pn * vn.z, pn * vn.w);
+            }
+#pragma unroll
+            for (int w = 0; w < DA_WAVES; ++w) {
+                const float f = expf(mred[w * 3 + hh] - M);     // waves without keys: m = -inf -> factor 0
+                const float4 ow = *reinterpret_cast<const float4*>(ored + (w * 3 + hh) * 64 + dq * 4);
+                L += lred[w * 3 + hh] * f;
+                O.x += ow.x * f; O.y += ow.y * f; O.z += ow.z * f; O.w += ow.w * f;
+            }
+        }
+        // F16-layout (B operand of the o_proj's 16x16x4 MFMA): column k = head*64 + 4*dq
+        const int head = 3 * g + hh, k = head * 64 + dq * 4;
+        const int rb = b >> 5, m = b & 31;
+        const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
+        reinterpret_cast<float4*>(a.attF16)[o4] = O;
+        if (dq == 0) {
+            a.att_m[((int64_t)sp * 9 + head) * a.rows + b] = M;
+            a.att_l[((int64_t)sp * 9 + head) * a.rows + b] = L;
+        }
+    }
+    kstamp(1, 6, dbg);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K3  o_proj with complete output.  grid (36 n16-tiles, RB), 16 waves; v_mfma_f32_16x16x4_f32, W in P16-layout.
+//     X = merge of the DEC_TS attention splits (coalesced F16 loads);  x_mid = x_new + X Wo^T
+//     writes x_mid row-major + F32-layout (gate/up operand) + per-tile sum of squares (down's RMS scale)
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+    __shared__ __attribute__((aligned(16))) float red[16 * 8 * 64];   // 32 KiB: [wave][acc reg 0..7][lane]
+    constexpr int TPW = 3, K16 = 36;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x, rb = blockIdx.y;
+    const int ml = lane & 15;
+    const float4* wp = reinterpret_cast<const float4*>(Wp16) + (int64_t)nt * K16 * 64 + lane;
+    // epilogue operand issued up front: thread (m, nq) of the 32 x 16 tile owns 4 consecutive columns
+    const int em = (tid >> 2) & 31, enq = tid & 3;
+    const int64_t erow = (int64_t)rb * 32 + em;
+    const float4 xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
+    const bool dbg = tid == 0 && nt == 0 && rb == 0;
+    kstamp(2, 0, dbg);
+
+    float4 w[TPW], os[TPW][2][DEC_TS];
+    float ms[TPW][2][DEC_TS], ls[TPW][2][DEC_TS];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + 16 * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
+        w[i] = wp[(int64_t)tc * 64];
+        if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int h = tc >> 2;                                        // tile = 16 k of head h
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t row = (int64_t)rb * 32 + ml + 16 * half;
+#pragma unroll
+            for (int s = 0; s < DEC_TS; ++s) {
+                ms[i][half][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
+                ls[i][half][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
+                os[i][half][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + half) * 64 + lane];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kstamp(2, 1, dbg);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        float4 xh[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // merge the key splits: x = sum_s f_s o_s / sum_s f_s l_s, f_s = exp(m_s - max m)
+            float M = ms[i][half][0];
+#pragma unroll
+            for (int s = 1; s < DEC_TS; ++s) M = fmaxf(M, ms[i][half][s]);
+            float L = 0.f;
+            float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < DEC_TS; ++s) {
+                const float f = expf(ms[i][half][s] - M);
+                L += ls[i][half][s] * f;
+                O.x += os[i][half][s].x * f; O.y += os[i][half][s].y * f;
+                O.z += os[i][half][s].z * f; O.w += os[i][half][s].w * f;
+            }
+            const float inv = 1.0f / L;
+            xh[half] = make_float4(O.x * inv, O.y * inv, O.z * inv, O.w * inv);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, xh[0].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, xh[1].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, xh[0].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, xh[1].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, xh[0].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, xh[1].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, xh[0].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, xh[1].w, acc1, 0, 0, 0);
+    }
+    kstamp(2, 2, dbg && acc0[0] == acc0[0]);
+    // D[i = n_local = 4*(lane>>4) + r][j = m_local = lane&15]; acc0 rows 0..15, acc1 rows 16..31
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(wave * 8 + r) * 64 + lane] = acc0[r];
+        red[(wave * 8 + 4 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+    kstamp(2, 3, dbg);
+    if (tid < 128) {
+        // columns n = 4*enq + r live in registers r = 0..3 of lane (em&15) + 16*enq, accumulator (em>>4)
+        const int src_lane = (em & 15) + 16 * enq, rbase = (em >> 4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += red[(wv * 8 + rbase + r) * 64 + src_lane];
+        const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
+        const int k = nt * 16 + enq * 4;
+        *reinterpret_cast<float4*>(a.xmidR + erow * 576 + k) = y;
+        reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, em, k)] = y;
+        float ss = f4ssq(y);
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        if (enq == 0) a.ssq[erow * 40 + nt] = ss;
+    }
+    kstamp(2, 4, dbg);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K4  full-K projection (gate/up and lm_head).  grid (n-tiles, 1, RB), 4 waves x 18 k-tiles, all 36 loads of a
+//     wave in flight; X in F32-layout.  OUT_GU: writes g/u in the down projection's F32-layout
+//     guF[rb][hidden/8][g|u][lane][4];  OUT_LOGITS: row-major logits + fused arg-max candidates per tile.
+// ----------------------------------------------------------------------------------------------------
+enum { OUT_GU = 0, OUT_LOGITS = 1 };
+template <int OUT>
+__global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
+                                                        const float* __restrict__ XF, int N) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    constexpr int KPW = 18;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x, rb = blockIdx.z;
+    const int k8_0 = wave * KPW;
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+    float4 w[KPW], x[KPW];
+    const bool dbg = tid == 0 && nt == 0 && rb == 0;
+    const int dslot = OUT == OUT_GU ? 3 : 5;
+    kstamp(dslot, 0, dbg);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) { w[i] = wp[i * 64]; x[i] = xp[i * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+    kstamp(dslot, 1, dbg);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], x[i]);
+    kstamp(dslot, 2, dbg && acc[0] == acc[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    kstamp(dslot, 3, dbg);
+    const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * gq + j;
+        v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) +
+               (red[(2 * 16 + r) * 64 + mm + 32 * hh] + red[(3 * 16 + r) * 64 + mm + 32 * hh]);
+    }
+    if (OUT == OUT_GU) {
+        // n-tile nt = 2*jj + is_up (pair-interleaved gate/up packing); hidden unit = 32*jj + 8*gq + 4*hh + (0..3)
+        const int jj = nt >> 1, is_up = nt & 1;
+        const int kd = 4 * jj + gq;                                   // k-tile of the down projection
+        reinterpret_cast<float4*>(a.guF)[((((int64_t)rb * 192 + kd) * 2 + is_up) * 64) + mm + 32 * hh] =
+            make_float4(v[0], v[1], v[2], v[3]);
+        kstamp(dslot, 4, dbg);
+    } else {
+        const int n = nt * 32 + 8 * gq + 4 * hh;
+        const int64_t row = (int64_t)rb * 32 + mm;
+        if (a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        // best (value, lowest index) of this 32-column tile per row (torch.argmax tie rule)
         __syncthreads();
         float bv = v[0];
         int bi = n;
@@ -110,264 +494,209 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const SkinnyArgs a) 
                 const int oi = reinterpret_cast<int*>(red)[256 + tid + 32 * q];
                 if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
             }
-            const int64_t o = (int64_t)(rb * 32 + tid) * gridDim.x + nt;
+            const int64_t o = ((int64_t)rb * 32 + tid) * gridDim.x + nt;
             a.cand_val[o] = best;
             a.cand_idx[o] = idx;
         }
     }
 }
 
-template <int KPW>
-static void launch_skinny_kpw(const SkinnyArgs& a, int KC, hipStream_t s) {
-    const dim3 grid((a.N + 31) / 32, KC, a.RB);
-    if (a.pro == PRO_SWIGLU) hipLaunchKernelGGL((skinny_splitk_kernel<KPW, PRO_SWIGLU, SK_KC_GU>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((skinny_splitk_kernel<KPW, PRO_PLAIN, 1>), grid, dim3(256), 0, s, a);
-}
-
-int skinny_kc_for(int K) {
-    // k8 tiles = K/8 must equal KC * 4 waves * KPW with KPW in {2,3,6,9,18}
-    const int K8 = K / 8;
-    if (K8 == 72) return 9;     // K = 576  -> KPW 2
-    if (K8 == 192) return 16;   // K = 1536 -> KPW 3
-    return 0;
-}
-
-void launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    const int K8 = a.K / 8;
-    const int KC = a.kc_out;
-    const int kpw = K8 / (KC * 4);
-    switch (kpw) {
-        case 2: launch_skinny_kpw<2>(a, KC, s); break;
-        case 3: launch_skinny_kpw<3>(a, KC, s); break;
-        case 6: launch_skinny_kpw<6>(a, KC, s); break;
-        case 9: launch_skinny_kpw<9>(a, KC, s); break;
-        case 18: launch_skinny_kpw<18>(a, KC, s); break;
-        default: break;  // validated by the engine
-    }
-}
-
-// ---- row-parallel finish: x_out = x_in + sum_kc P[kc]; optional RMSNorm -> xn -------------------------------
-// One workgroup per batch row; replaces the residual adds and LlamaRMSNorm of the reference layer.
-// KC is a compile-time constant so the KC slab loads are issued together (one L2 round trip, not KC).
-template <int KC>
-__global__ __launch_bounds__(192) void rows_finish_kernel(const float* __restrict__ x_in, const float* __restrict__ P,
-                                                          int64_t slab_stride, float* __restrict__ x_out,
-                                                          const float* __restrict__ norm_w, float eps,
-                                                          float* __restrict__ xn, int C, int32_t* inc_word) {
-    __shared__ float part[3];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const int nv = C >> 2;
-    // the first finish of a decode step advances the position word: no kernel of the previous step reads it any
-    // more, and this kernel does not read it
-    if (inc_word && row == 0 && tid == 0) *inc_word = *inc_word + 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < nv) {
-        float4 p[KC > 0 ? KC : 1];
-        v = reinterpret_cast<const float4*>(x_in + (int64_t)row * C)[tid];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) p[s] = reinterpret_cast<const float4*>(P + s * slab_stride + (int64_t)row * C)[tid];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) { v.x += p[s].x; v.y += p[s].y; v.z += p[s].z; v.w += p[s].w; }
-        if (x_out && KC > 0) reinterpret_cast<float4*>(x_out + (int64_t)row * C)[tid] = v;
-    }
-    if (norm_w) {
-        float ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        ss = wave_sum(ss);
-        if ((tid & 63) == 0) part[tid >> 6] = ss;
-        __syncthreads();
-        const float r = 1.0f / sqrtf((part[0] + part[1] + part[2]) / (float)C + eps);
-        if (tid < nv) {
-            const float4 w = reinterpret_cast<const float4*>(norm_w)[tid];
-            float4 y;
-            y.x = __fmul_rn(w.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(w.y, __fmul_rn(v.y, r));
-            y.z = __fmul_rn(w.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(w.w, __fmul_rn(v.w, r));
-            reinterpret_cast<float4*>(xn + (int64_t)row * C)[tid] = y;
-        }
-    }
-}
-void launch_rows_finish(const float* x_in, const float* P, int kc, int64_t slab_stride, float* x_out,
-                        const float* norm_w, float eps, float* xn, int rows, int C, int32_t* inc_word, hipStream_t s) {
-#define MELLOW_RF(KC) hipLaunchKernelGGL((rows_finish_kernel<KC>), dim3(rows), dim3(192), 0, s, x_in, P, slab_stride, x_out, norm_w, eps, xn, C, inc_word)
-    switch (kc) {
-        case 0: MELLOW_RF(0); break;
-        case SK_KC_O: MELLOW_RF(SK_KC_O); break;       // == SK_KC_QKV
-        case SK_KC_DOWN: MELLOW_RF(SK_KC_DOWN); break;
-        default: break;   // validated by the engine
-    }
-#undef MELLOW_RF
-}
-
 // ----------------------------------------------------------------------------------------------------
-// decode attention (flash-decoding inside one workgroup).  grid (kv_heads=3, B); 1024 threads = 16 waves.
-//   qkv split-K slabs P[kc][rows][960] (q: 9 heads x 64 | k: 3 x 64 | v: 3 x 64, no RoPE yet), summed here.
-//   position of the new token = *d_pos (number of keys already in the pages).
-// Each wave owns an interleaved set of 4-key groups: it issues the K and V loads of up to DA_G groups at
-// once (2 KiB per group in flight), computes the 3 GQA heads' scores from ONE pass over K, does its own
-// softmax statistics (max / sum) in registers, accumulates P.V, and only at the end the 16 waves'
-// (m, l, o) triples are combined through LDS — one barrier instead of a block-wide softmax.
+// K5  down projection, split-K.  grid (18 n-tiles, DEC_KC_DOWN, RB), 6 waves x 8 k-tiles.
+//     r2[m] = rsqrt(mean(x_mid[m]^2) + eps) from the o_proj's per-tile sums;  X = silu(r2 g) * (r2 u)
+//     out: down slabs row-major (attention / final norm) + F32-layout (next layer's qkv)
 // ----------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 16;
-constexpr int DA_G = 8;          // 4-key groups in flight per wave per chunk (512 keys per chunk per block)
-
-template <int KC>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
-    const float* __restrict__ qkv_parts, int64_t slab_stride, float* __restrict__ k_cache,
-    float* __restrict__ v_cache, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-    const int32_t* __restrict__ d_pos, float* __restrict__ o, int Tmax) {
-    __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
-    __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
-    __shared__ __attribute__((aligned(16))) float ored[DA_WAVES * 3 * 64];
-    __shared__ float mred[DA_WAVES * 3], lred[DA_WAVES * 3];
-
-    const int g = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+    __shared__ __attribute__((aligned(16))) float red[6 * 16 * 64];   // 24 KiB
+    constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = *d_pos;          // keys 0..pos-1 are cached; the new key is key `pos`
-    const float* row = qkv_parts + (int64_t)b * 960;
-    float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
-    float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
-
-    // ---- sum the split-K slabs, RoPE (rotate-half) the 3 query heads and the new key, append to the pages ----
-    if (tid < 4 * 32) {
-        const int hsel = tid >> 5, i = tid & 31;   // hsel 0..2 = query head 3g+hsel, 3 = new key
-        const float c = rope_cos[(int64_t)pos * 32 + i], sn = rope_sin[(int64_t)pos * 32 + i];
-        const int col = hsel < 3 ? (3 * g + hsel) * 64 : 576 + g * 64;
-        float a1[KC], a2[KC];
+    const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
+    const int m = lane & 31;
+    const int k8_0 = (kc * 6 + wave) * KPW;
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    const float4* gp = reinterpret_cast<const float4*>(a.guF) + (((int64_t)rb * 192 + k8_0) * 2) * 64 + lane;
+    const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + m) * 40);
+    const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
+    kstamp(4, 0, dbg);
+    float4 s4[9], w[KPW], g4[KPW], u4[KPW];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-            a1[s] = row[s * slab_stride + col + i];
-            a2[s] = row[s * slab_stride + col + i + 32];
-        }
-        float x1 = a1[0], x2 = a2[0];
+    for (int j = 0; j < 9; ++j) s4[j] = sq[j];
 #pragma unroll
-        for (int s = 1; s < KC; ++s) { x1 += a1[s]; x2 += a2[s]; }
-        const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sn));
-        const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
-        if (hsel < 3) {
-            qs[hsel * 64 + i] = o1 * 0.125f;        // head_dim^-0.5 = 1/8 exactly
-            qs[hsel * 64 + i + 32] = o2 * 0.125f;
-        } else {
-            knew[i] = o1; knew[i + 32] = o2;
-            kpage[(int64_t)pos * 64 + i] = o1; kpage[(int64_t)pos * 64 + i + 32] = o2;
-        }
-    } else if (tid < 4 * 32 + 64) {
-        const int i = tid - 128;
-        float a1[KC];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) a1[s] = row[s * slab_stride + 768 + g * 64 + i];
-        float v = a1[0];
-#pragma unroll
-        for (int s = 1; s < KC; ++s) v += a1[s];
-        vnew[i] = v;
-        vpage[(int64_t)pos * 64 + i] = v;
+    for (int i = 0; i < KPW; ++i) {
+        w[i] = wp[i * 64];
+        g4[i] = gp[(i * 2) * 64];
+        u4[i] = gp[(i * 2 + 1) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    kstamp(4, 1, dbg);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) ss += (s4[j].x + s4[j].y) + (s4[j].z + s4[j].w);
+    const float r = 1.0f / sqrtf(ss / 576.0f + a.eps);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        float4 xv;
+        xv.x = __fmul_rn(siluf_(g4[i].x * r), u4[i].x * r); xv.y = __fmul_rn(siluf_(g4[i].y * r), u4[i].y * r);
+        xv.z = __fmul_rn(siluf_(g4[i].z * r), u4[i].z * r); xv.w = __fmul_rn(siluf_(g4[i].w * r), u4[i].w * r);
+        acc = mfma4(acc, w[i], xv);
+    }
+    kstamp(4, 2, dbg && acc[0] == acc[0]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[q];
     __syncthreads();
-
-    // lane -> (key sub = lane>>4, dim quad = lane&15); one wave instruction covers 4 keys x 64 dims
-    const int sub = lane >> 4, quad = lane & 15;
-    float4 q4[3];
+    kstamp(4, 3, dbg);
+    if (tid < 256) {
+        const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
+        float v[4];
 #pragma unroll
-    for (int hh = 0; hh < 3; ++hh) q4[hh] = *reinterpret_cast<const float4*>(qs + hh * 64 + quad * 4);
-    const int ngroups = (pos + 3) >> 2;   // groups of 4 cached keys
-    float m_run[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float l_run[3] = {0.f, 0.f, 0.f};      // per-lane partial (this lane's keys only)
-    float4 acc[3];
+        for (int j = 0; j < 4; ++j) {
+            const int q = 4 * gq + j;
+            float sacc = 0.f;
 #pragma unroll
-    for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int g0 = wave; g0 < ngroups; g0 += DA_WAVES * DA_G) {
-        float4 k4[DA_G], v4[DA_G];
-#pragma unroll
-        for (int u = 0; u < DA_G; ++u) {
-            const int t = (g0 + u * DA_WAVES) * 4 + sub;
-            const int tc = t < pos ? t : pos - 1;   // pos >= 1 always (a prefix precedes)
-            k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
-            v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
+            for (int wv = 0; wv < 6; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];
+            v[j] = sacc;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        float sc[DA_G][3];
-        float cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int u = 0; u < DA_G; ++u) {
-            const int t = (g0 + u * DA_WAVES) * 4 + sub;
-#pragma unroll
-            for (int hh = 0; hh < 3; ++hh) {
-                float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;
-                sv += __shfl_xor(sv, 8, 64);
-                sv += __shfl_xor(sv, 4, 64);
-                sv += __shfl_xor(sv, 2, 64);
-                sv += __shfl_xor(sv, 1, 64);
-                sv = t < pos ? sv : -INFINITY;
-                sc[u][hh] = sv;
-                cmax[hh] = fmaxf(cmax[hh], sv);
-            }
-        }
-#pragma unroll
-        for (int hh = 0; hh < 3; ++hh) {
-            float cm = cmax[hh];
-            cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-            const float m_new = fmaxf(m_run[hh], cm);       // finite: the chunk's first key (t = 4*g0) is valid
-            const float alpha = expf(m_run[hh] - m_new);    // exp(-inf) = 0 on the first chunk
-            m_run[hh] = m_new;
-            float lsum = 0.f;
-            float4 a = make_float4(acc[hh].x * alpha, acc[hh].y * alpha, acc[hh].z * alpha, acc[hh].w * alpha);
-#pragma unroll
-            for (int u = 0; u < DA_G; ++u) {
-                const float p = expf(sc[u][hh] - m_new);    // masked keys: exp(-inf) = 0
-                lsum += p;
-                a.x += p * v4[u].x; a.y += p * v4[u].y; a.z += p * v4[u].z; a.w += p * v4[u].w;
-            }
-            acc[hh] = a;
-            l_run[hh] = l_run[hh] * alpha + lsum;
-        }
+        const int n = nt * 32 + 8 * gq + 4 * hh;
+        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a.dslabR + ((int64_t)kc * a.rows + rb * 32 + mm) * 576 + n) = o;
+        reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
     }
-    // reduce the 4 key-subs of the wave; publish (m, l, o) of the wave
+    kstamp(4, 4, dbg);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// row-parallel helpers (one workgroup per batch row)
+// ----------------------------------------------------------------------------------------------------
+// final RMSNorm: xn = w * ((x_mid + sum down slabs) * rsqrt(mean^2 + eps)) -> F32-layout operand of the lm_head
+template <int KCD>
+__global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, const float* __restrict__ norm_w) {
+    __shared__ float part[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int xi = tid < 144 ? tid : 0;
+    float4 v = reinterpret_cast<const float4*>(a.xmidR + (int64_t)b * 576)[xi];
+    float4 xs[KCD > 0 ? KCD : 1];
 #pragma unroll
-    for (int hh = 0; hh < 3; ++hh) {
-        float l = l_run[hh];                 // identical across the 16 quads of a sub; sum over the 4 subs
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabR + ((int64_t)s * a.rows + b) * 576)[xi];
+    const float4 wv = reinterpret_cast<const float4*>(norm_w)[xi];
 #pragma unroll
-        for (int off = 16; off < 64; off <<= 1) {
-            acc[hh].x += __shfl_xor(acc[hh].x, off, 64);
-            acc[hh].y += __shfl_xor(acc[hh].y, off, 64);
-            acc[hh].z += __shfl_xor(acc[hh].z, off, 64);
-            acc[hh].w += __shfl_xor(acc[hh].w, off, 64);
-        }
-        if (sub == 0) *reinterpret_cast<float4*>(ored + (wave * 3 + hh) * 64 + quad * 4) = acc[hh];
-        if (lane == 0) { mred[wave * 3 + hh] = m_run[hh]; lred[wave * 3 + hh] = l; }
-    }
+    for (int s = 0; s < KCD; ++s) v = f4add(v, xs[s]);
+    float ss = tid < 144 ? f4ssq(v) : 0.f;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
     __syncthreads();
-    if (tid < 192) {
-        const int hh = tid >> 6, d = tid & 63;
-        float snew = 0.f;                    // score of the new key (q . k_new, both in LDS)
-#pragma unroll
-        for (int i = 0; i < 64; ++i) snew += qs[hh * 64 + i] * knew[i];
-        float M = snew;
-#pragma unroll
-        for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, mred[w * 3 + hh]);
-        const float pn = expf(snew - M);
-        float L = pn, O = pn * vnew[d];
-#pragma unroll
-        for (int w = 0; w < DA_WAVES; ++w) {
-            const float f = expf(mred[w * 3 + hh] - M);     // waves without keys: m = -inf -> factor 0
-            L += lred[w * 3 + hh] * f;
-            O += ored[(w * 3 + hh) * 64 + d] * f;
-        }
-        o[(int64_t)b * 576 + (3 * g + hh) * 64 + d] = O / L;
+    const float r = 1.0f / sqrtf((part[0] + part[1] + part[2]) / 576.0f + a.eps);
+    if (tid < 144) {
+        float4 y;
+        y.x = __fmul_rn(wv.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(wv.y, __fmul_rn(v.y, r));
+        y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
+        reinterpret_cast<float4*>(a.xnF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = y;
     }
 }
 
-void launch_decode_attention(const float* qkv_parts, int kc, int64_t slab_stride, float* k_cache, float* v_cache,
-                             const float* rope_cos, const float* rope_sin, const int32_t* d_pos, float* o, int B,
-                             int Tmax, hipStream_t s) {
-    (void)kc;  // == SK_KC_QKV, validated by the engine
-    hipLaunchKernelGGL((decode_attention_kernel<SK_KC_QKV>), dim3(3, B), dim3(DA_WAVES * 64), 0, s, qkv_parts, slab_stride,
-                       k_cache, v_cache, rope_cos, rope_sin, d_pos, o, Tmax);
+// arg-max over the lm_head's per-tile candidates, fused with the loop bookkeeping of reference wrapper.py:232-249:
+// record the token at column (*d_pos - T0 + 1), track stop ids, and gather its embedding row (embed_tokens,
+// wrapper.py:237) as the next step's residual stream (row-major + F32-layout).
+__global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n, int32_t* __restrict__ tokens,
+                                                         const float* __restrict__ embed, int write_x,
+                                                         int32_t* __restrict__ out_tokens, int max_len, int T0,
+                                                         int stop_id, int32_t* seen_stop, int32_t* n_seen) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int tok_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        const float v = a.cand_val[(int64_t)b * n + i];
+        const int id = a.cand_idx[(int64_t)b * n + i];
+        if (v > best || (v == best && id < idx)) { best = v; idx = id; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        tokens[b] = idx;
+        tok_s = idx;
+        if (out_tokens) {
+            const int step = *a.d_pos - T0 + 1;
+            if (step >= 0 && step < max_len) out_tokens[(int64_t)b * max_len + step] = idx;
+            if (idx == stop_id && seen_stop[b] == 0) {
+                seen_stop[b] = 1;
+                atomicAdd(n_seen, 1);
+            }
+        }
+    }
+    if (write_x) {
+        __syncthreads();
+        if (tid < 144) {
+            const float4 e = reinterpret_cast<const float4*>(embed + (int64_t)tok_s * 576)[tid];
+            reinterpret_cast<float4*>(a.xmidR + (int64_t)b * 576)[tid] = e;
+            reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
+        }
+    }
 }
 
-// ---- arg-max with first-index ties (torch.argmax, reference wrapper.py:232) ---------------------------------
-// full-row version (taps / mellow_argmax): one workgroup per row, float4 loads
+// rows -> residual stream (row-major + F32-layout): src row b = in[row_of(b)]
+__global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, const float* __restrict__ in, int64_t ld,
+                                                            const int32_t* __restrict__ row_ids, int T_last) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t src = row_ids ? (int64_t)row_ids[b] : (int64_t)b * T_last + (T_last - 1);
+    if (tid < 144) {
+        const float4 e = reinterpret_cast<const float4*>(in + src * ld)[tid];
+        reinterpret_cast<float4*>(a.xmidR + (int64_t)b * 576)[tid] = e;
+        reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------
+void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStream_t s) {
+    const dim3 grid(30, DEC_KC_QKV, a.RB);
+    if (kcd == 0) hipLaunchKernelGGL((dec_qkv_kernel<0>), grid, dim3(256), 0, s, a, Wp, K8p);
+    else hipLaunchKernelGGL((dec_qkv_kernel<DEC_KC_DOWN>), grid, dim3(256), 0, s, a, Wp, K8p);
+}
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, hipStream_t s) {
+    const dim3 grid(3, a.rows, DEC_TS);
+    if (kcd == 0) hipLaunchKernelGGL((dec_attn_kernel<0>), grid, dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
+    else hipLaunchKernelGGL((dec_attn_kernel<DEC_KC_DOWN>), grid, dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
+}
+void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
+    hipLaunchKernelGGL(dec_oproj_kernel, dim3(36, a.RB), dim3(1024), 0, s, a, Wp16);
+}
+void launch_dec_gateup(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
+    hipLaunchKernelGGL((dec_fullk_kernel<OUT_GU>), dim3(96, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xmidF, 3072);
+}
+void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
+    hipLaunchKernelGGL(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(384), 0, s, a, Wp, K8p);
+}
+void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s) {
+    if (kcd == 0) hipLaunchKernelGGL((dec_final_norm_kernel<0>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+    else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+}
+void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
+}
+void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
+                       int32_t* out_tokens, int max_len, int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(B), dim3(256), 0, s, a, n_tiles, tokens, embed, write_x, out_tokens, max_len,
+                       T0, stop_id, seen_stop, n_seen);
+}
+void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(dec_load_rows_kernel, dim3(B), dim3(192), 0, s, a, in, ld, row_ids, T_last);
+}
+
+// ---- full-row arg-max (mellow_argmax tap): torch.argmax tie rule, float4 loads --------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int64_t ld,
                                                       int32_t* __restrict__ tokens) {
     __shared__ float bv[16];
@@ -400,114 +729,22 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s) {
     hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, V, ld, tokens);
 }
-// candidate version: per-row reduction of the lm_head's per-tile (value, index) candidates, fused with the loop
-// bookkeeping of reference wrapper.py:232-249: record the token at column (*d_pos - T0 + 1), track stop ids,
-// and gather its embedding row as the next step's input (embed_tokens, wrapper.py:237).
-__global__ __launch_bounds__(256) void argmax_cand_kernel(const float* __restrict__ cv, const int32_t* __restrict__ ci,
-                                                          int n, int32_t* __restrict__ tokens,
-                                                          const float* __restrict__ embed, int H, float* __restrict__ x,
-                                                          int32_t* __restrict__ out_tokens, int max_len,
-                                                          const int32_t* __restrict__ d_pos, int T0, int stop_id,
-                                                          int32_t* seen_stop, int32_t* n_seen) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    __shared__ int tok_s;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-        const float v = cv[(int64_t)b * n + i];
-        const int id = ci[(int64_t)b * n + i];
-        if (v > best || (v == best && id < idx)) { best = v; idx = id; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-    }
-    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        tokens[b] = idx;
-        tok_s = idx;
-        if (out_tokens) {
-            const int step = *d_pos - T0 + 1;
-            if (step >= 0 && step < max_len) out_tokens[(int64_t)b * max_len + step] = idx;
-            if (idx == stop_id && seen_stop[b] == 0) {
-                seen_stop[b] = 1;
-                atomicAdd(n_seen, 1);
-            }
-        }
-    }
-    if (x) {
-        __syncthreads();
-        const float4* src = reinterpret_cast<const float4*>(embed + (int64_t)tok_s * H);
-        float4* dst = reinterpret_cast<float4*>(x + (int64_t)b * H);
-        for (int i = tid; i < H / 4; i += 256) dst[i] = src[i];
-    }
-}
-void launch_argmax_cand(const float* cv, const int32_t* ci, int B, int n, int32_t* tokens, const float* embed, int H,
-                        float* x, int32_t* out_tokens, int max_len, const int32_t* d_pos, int T0, int stop_id,
-                        int32_t* seen_stop, int32_t* n_seen, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_cand_kernel, dim3(B), dim3(256), 0, s, cv, ci, n, tokens, embed, H, x, out_tokens, max_len,
-                       d_pos, T0, stop_id, seen_stop, n_seen);
-}
 
-// ---- embedding gather of the new tokens + on-device loop bookkeeping (wrapper.py:236-249) ----------------------
-__global__ void embed_and_record_kernel(const float* __restrict__ embed, const int32_t* __restrict__ tokens, int H,
-                                        float* __restrict__ x, int32_t* __restrict__ out_tokens, int max_len,
-                                        const int32_t* __restrict__ d_step, int stop_id, int32_t* seen_stop,
-                                        int32_t* n_seen) {
-    // grid = B blocks; block b copies embedding row tokens[b] into x[b] and records the token at column *d_step
-    const int b = blockIdx.x;
-    const int tok = tokens[b];
-    if (x) {
-        const float4* src = reinterpret_cast<const float4*>(embed + (int64_t)tok * H);
-        float4* dst = reinterpret_cast<float4*>(x + (int64_t)b * H);
-        for (int i = threadIdx.x; i < H / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    if (threadIdx.x == 0 && out_tokens) {
-        const int step = *d_step;
-        if (step < max_len) out_tokens[(int64_t)b * max_len + step] = tok;
-        if (tok == stop_id && seen_stop[b] == 0) {
-            seen_stop[b] = 1;
-            atomicAdd(n_seen, 1);
-        }
+// P16 packing: out[nt][k16][lane][4] = W[nt*16 + (lane&15)][k16*16 + 4*(lane>>4) + j]
+__global__ void pack_weight16_kernel(const float* __restrict__ w, int N, int K, float* __restrict__ out) {
+    const int64_t total = (int64_t)(N / 16) * (K / 16) * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int64_t tile = i >> 6;
+        const int k16 = (int)(tile % (K / 16)), nt = (int)(tile / (K / 16));
+        const int n = nt * 16 + (lane & 15), k0 = k16 * 16 + 4 * (lane >> 4);
+        reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(w + (int64_t)n * K + k0);
     }
 }
-__global__ void advance_kernel(int32_t* p) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *p = *p + 1;
-}
-void launch_advance(int32_t* p, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, p); }
-void launch_embed_and_record(const float* embed, const int32_t* tokens, int B, int H, float* x, int32_t* out_tokens,
-                             int max_len, int32_t* d_step, int stop_id, int32_t* seen_stop, int32_t* n_seen,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(embed_and_record_kernel, dim3(B), dim3(64), 0, s, embed, tokens, H, x, out_tokens, max_len,
-                       (const int32_t*)d_step, stop_id, seen_stop, n_seen);
-    if (out_tokens) launch_advance(d_step, s);   // separate launch: every block has read *d_step before it moves
-}
-
-__global__ void gather_rows_kernel(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ rows, int C,
-                                   float* __restrict__ out, int64_t ld_out) {
-    const int r = blockIdx.x;
-    const int src = rows ? rows[r] : r;
-    for (int i = threadIdx.x; i < C; i += blockDim.x) out[(int64_t)r * ld_out + i] = in[(int64_t)src * ld_in + i];
-}
-void launch_gather_rows(const float* in, int64_t ld_in, const int32_t* rows, int n, int C, float* out, int64_t ld_out,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, in, ld_in, rows, C, out, ld_out);
-}
-
-__global__ void take_last_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
-    const int b = blockIdx.x;
-    const float* src = x + ((int64_t)b * T + (T - 1)) * C;
-    for (int i = threadIdx.x; i < C; i += blockDim.x) out[(int64_t)b * C + i] = src[i];
-}
-void launch_take_last(const float* x, int B, int T, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(take_last_kernel, dim3(B), dim3(256), 0, s, x, T, C, out);
+void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s) {
+    const int64_t total = (int64_t)(N / 16) * (K / 16) * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight16_kernel, dim3(blocks), dim3(256), 0, s, w, N, K, out);
 }
 
 }  // namespace mellow

@@ -93,7 +93,9 @@ struct MergeW {
     Packed red;
 };
 struct LMLayerW {
-    Packed qkv, o, gateup, down;
+    Packed qkv, o, gateup, down;       // prefill (plain weights, P-layout); `down` is also the decode operand
+    Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
+    float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
     float *in_ln, *post_ln;
 };
 
@@ -136,7 +138,9 @@ struct mellow_engine {
     };
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
-    Buf dx, dxn, pq, dattn, po, pg, pd, dlogits, cand;
+    Buf dec;                                   // one arena for the decode-step buffers (DecArgs)
+    Buf dlogits, cand;
+    DecArgs da;
     int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
     int kv_B = 0, kv_Tmax = 0;                // current page geometry
     int cur_B = 0, cur_pos = 0;               // host mirror of the decode state
@@ -377,8 +381,8 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     for (void* p : e->allocs) hipFree(p);
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
-                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dx,
-                                  &e->dxn, &e->pq, &e->dattn, &e->po, &e->pg, &e->pd, &e->dlogits, &e->cand};
+                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dec,
+                                  &e->dlogits, &e->cand};
     for (auto* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : e->taps)
@@ -459,6 +463,18 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
     HIPCHK(hipFree(d0));
     if (d1) HIPCHK(hipFree(d1));
     *out = p;
+    return 0;
+}
+static int make_packed16(mellow_engine* e, const float* w, int N, int K, float** out) {
+    if (N % 16 || K % 16) return fail("P16 packing needs N and K multiples of 16");
+    float* d0 = nullptr;
+    HIPCHK(hipMalloc(&d0, (size_t)N * K * sizeof(float)));
+    HIPCHK(hipMemcpy(d0, w, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice));
+    CHK(dev_alloc(e, out, (size_t)N * K));
+    launch_pack_weight16(d0, N, K, *out, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(d0));
     return 0;
 }
 static int pack_key(mellow_engine* e, const std::string& k, int N, int K, Packed* out) {
@@ -624,6 +640,21 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(pack_key(e, p + "mlp.down_proj.weight", H, I, &w.down));
         CHK(up_vec(e, p + "input_layernorm.weight", H, &w.in_ln));
         CHK(up_vec(e, p + "post_attention_layernorm.weight", H, &w.post_ln));
+        {   // decode copies: fold the norm weights into the columns; 16-row tiles for the complete-output o_proj
+            const HostTensor *l1 = get(e, p + "input_layernorm.weight"), *l2 = get(e, p + "post_attention_layernorm.weight");
+            std::vector<float> f(qkv);
+            for (int n = 0; n < 960; ++n)
+                for (int kk = 0; kk < H; ++kk) f[(size_t)n * H + kk] = qkv[(size_t)n * H + kk] * l1->f()[kk];
+            CHK(make_packed(e, f.data(), nullptr, 960, H, &w.qkv_f));
+            std::vector<float> gf((size_t)I * H), uf((size_t)I * H);
+            for (int n = 0; n < I; ++n)
+                for (int kk = 0; kk < H; ++kk) {
+                    gf[(size_t)n * H + kk] = g->f()[(size_t)n * H + kk] * l2->f()[kk];
+                    uf[(size_t)n * H + kk] = u->f()[(size_t)n * H + kk] * l2->f()[kk];
+                }
+            CHK(make_packed(e, gf.data(), uf.data(), I, H, &w.gateup_f));
+            CHK(make_packed16(e, get(e, p + "self_attn.o_proj.weight")->f(), H, 576, &w.o16));
+        }
         e->layers.push_back(w);
     }
     CHK(up_vec(e, L + "model.norm.weight", H, &e->final_norm));
@@ -824,7 +855,6 @@ static int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samp
 
 // ---- LM ----------------------------------------------------------------------------------------------------------------------
 static inline int rb_of(int B) { return (B + 31) / 32; }
-static const int kKcQkv = SK_KC_QKV, kKcO = SK_KC_O, kKcGu = SK_KC_GU, kKcDown = SK_KC_DOWN;  // kernels.h
 static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
 
 static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
@@ -844,35 +874,36 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         CHK(ensure(e, e->vcache, kv_layer_floats(e) * e->cfg.num_layers));
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
     }
-    const bool fresh = e->dx.cap < (size_t)Bp * 576;
-    CHK(ensure(e, e->dx, (size_t)Bp * 576));
-    CHK(ensure(e, e->dxn, (size_t)Bp * 576));
-    CHK(ensure(e, e->pq, (size_t)kKcQkv * Bp * 960));
-    CHK(ensure(e, e->dattn, (size_t)Bp * 576));
-    CHK(ensure(e, e->po, (size_t)kKcO * Bp * 576));
-    CHK(ensure(e, e->pg, (size_t)kKcGu * Bp * 3072));
-    CHK(ensure(e, e->pd, (size_t)kKcDown * Bp * 576));
-    CHK(ensure(e, e->dlogits, (size_t)Bp * e->cfg.vocab_size));
-    CHK(ensure(e, e->cand, (size_t)2 * Bp * (e->cfg.vocab_size / 32)));
-    if (fresh) {
-        // padded batch rows are computed but never read back; keep them finite
-        HIPCHK(hipMemsetAsync(e->dx.p, 0, (size_t)Bp * 576 * 4, e->stream));
-        if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+    {
+        // carve the decode-step buffers out of one arena (all sizes are multiples of 64 floats = 256 B)
+        const size_t RB = (size_t)Bp / 32, V = (size_t)e->cfg.vocab_size;
+        const size_t n_x = (size_t)Bp * 576;
+        size_t off = 0;
+        auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+        const size_t o_xmidR = take(n_x), o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x);
+        const size_t o_dslabR = take(DEC_KC_DOWN * n_x), o_dslabF = take(DEC_KC_DOWN * n_x);
+        const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
+        const size_t o_att = take((size_t)DEC_TS * n_x), o_am = take((size_t)DEC_TS * 9 * Bp), o_al = take((size_t)DEC_TS * 9 * Bp);
+        const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 2 * 256);
+        const bool fresh = e->dec.cap < off;
+        CHK(ensure(e, e->dec, off));
+        CHK(ensure(e, e->dlogits, (size_t)Bp * V));
+        CHK(ensure(e, e->cand, (size_t)2 * Bp * (V / 32)));
+        if (fresh) {
+            // padded batch rows are computed but never read back; start from finite values
+            HIPCHK(hipMemsetAsync(e->dec.p, 0, off * sizeof(float), e->stream));
+            if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+        }
+        float* p = e->dec.p;
+        DecArgs& a = e->da;
+        a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0;
+        a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+        a.xmidR = p + o_xmidR; a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
+        a.dslabR = p + o_dslabR; a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4);
+        a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu;
+        a.logits = e->dlogits.p; a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * (V / 32));
     }
     if (Bp > 1024) return fail("batch too large for the decode state block");
-    return 0;
-}
-
-static int run_skinny(mellow_engine* e, const SkinnyArgs& a) {
-    ProfScope ps(e, PF_SKINNY, 2.0 * 32 * a.RB * (double)a.K * a.N, (double)a.K * a.N * 4);
-    launch_skinny(a, e->stream);
-    return 0;
-}
-static int run_finish(mellow_engine* e, const float* P, int kc, const float* norm_w, int B, int32_t* inc_word) {
-    const int Bp = rb_of(B) * 32;
-    ProfScope ps(e, PF_NORM, 0, (double)(kc + 3) * Bp * 576 * 4);
-    launch_rows_finish(e->dx.p, P, kc, (int64_t)Bp * 576, e->dx.p, norm_w, e->cfg.rms_norm_eps, e->dxn.p, Bp, 576, inc_word,
-                       e->stream);
     return 0;
 }
 
@@ -884,22 +915,16 @@ struct RecordArgs {
     bool embed_next = false;
 };
 
-// final norm + lm_head (+ fused per-tile arg-max candidates) on dx (+ pending down-proj slabs) -> dlogits, d_tokens
-static int run_lm_head(mellow_engine* e, int B, int pending_kc, const RecordArgs* rec) {
-    const int Bp = rb_of(B) * 32, NT = e->cfg.vocab_size / 32;
-    CHK(run_finish(e, e->pd.p, pending_kc, e->final_norm, B, nullptr));
-    SkinnyArgs a;
-    a.X = e->dxn.p; a.ldx = 576; a.K = 576; a.Wp = e->lm_head.p; a.K8p = e->lm_head.KP / 8; a.N = e->cfg.vocab_size;
-    a.Y = e->dlogits.p; a.ldy = e->cfg.vocab_size; a.RB = rb_of(B); a.kc_out = 1; a.slab_rows_out = Bp;
-    a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * NT);
-    CHK(run_skinny(e, a));
-    {
-        ProfScope ps(e, PF_MISC, 0, 0);
-        launch_argmax_cand(a.cand_val, a.cand_idx, B, NT, e->d_tokens, e->embed, 576,
-                           (rec && rec->embed_next) ? e->dx.p : nullptr, rec ? rec->out_tokens : nullptr,
-                           rec ? rec->max_len : 0, e->d_pos, e->cfg.prefix_len, rec ? rec->stop_id : 0, e->d_seen,
-                           e->d_nseen, e->stream);
-    }
+// final norm (+ pending down slabs) + lm_head with fused per-tile arg-max candidates -> dlogits, d_tokens
+static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArgs* rec) {
+    const int NT = e->cfg.vocab_size / 32, Bp = e->da.rows;
+    { ProfScope ps(e, PF_NORM, 0, (double)(pending_kcd + 2) * Bp * 576 * 4);
+      launch_dec_final_norm(e->da, e->final_norm, pending_kcd, e->stream); }
+    { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * e->cfg.vocab_size, 576.0 * e->cfg.vocab_size * 4);
+      launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
+    { ProfScope ps(e, PF_MISC, 0, 0);
+      launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? rec->out_tokens : nullptr,
+                        rec ? rec->max_len : 0, e->cfg.prefix_len, rec ? rec->stop_id : 0, e->d_seen, e->d_nseen, e->stream); }
     return 0;
 }
 
@@ -942,7 +967,7 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
             CHK(run_gemm(e, g));
         }
     }
-    { ProfScope ps(e, PF_MISC, 0, 0); launch_take_last(x, B, T, 576, e->dx.p, s); }
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_dec_load_rows(e->da, B, x, 576, nullptr, T, s); }
     // position word = index of the LAST cached token; the first kernel of every decode step advances it, so the
     // arg-max below records its token at column (*d_pos - prefix_len + 1) = 0
     e->cur_B = B;
@@ -954,41 +979,31 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
     return 0;
 }
 
-// the 30 decode layers + head on dx at position *d_pos (enqueue only; capture-safe).
-// Per layer: finish+norm | qkv split-K | attention | o_proj split-K | finish+norm | gate/up split-K | down split-K
+// the 30 decode layers + head at position *d_pos (enqueue only; capture-safe).  5 launches per layer (decode.hip):
+//   qkv split-K | attention (RMS scale, RoPE, KV append, key-split flash decoding) | o_proj (merge + residual) |
+//   gate/up | down split-K (RMS scale, SwiGLU); the down slabs are summed by the next layer's qkv/attention.
 static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec) {
     hipStream_t s = e->stream;
-    const int RB = rb_of(B), Bp = RB * 32;
+    const int Bp = e->da.rows;
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const LMLayerW& w = e->layers[l];
         float* kc = e->kcache.p + kv_layer_floats(e) * l;
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
-        CHK(run_finish(e, e->pd.p, l == 0 ? 0 : kKcDown, w.in_ln, B, l == 0 ? e->d_pos : nullptr));
-        SkinnyArgs a;
-        a.X = e->dxn.p; a.ldx = 576; a.K = 576; a.Wp = w.qkv.p; a.K8p = w.qkv.KP / 8; a.N = 960; a.Y = e->pq.p; a.ldy = 960;
-        a.RB = RB; a.kc_out = kKcQkv; a.slab_rows_out = Bp;
-        CHK(run_skinny(e, a));
-        {
-            ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1),
-                         2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
-            launch_decode_attention(e->pq.p, kKcQkv, (int64_t)Bp * 960, kc, vc, e->rope_cos, e->rope_sin, e->d_pos,
-                                    e->dattn.p, Bp, e->kv_Tmax, s);
-        }
-        SkinnyArgs o;
-        o.X = e->dattn.p; o.ldx = 576; o.K = 576; o.Wp = w.o.p; o.K8p = w.o.KP / 8; o.N = 576; o.Y = e->po.p; o.ldy = 576;
-        o.RB = RB; o.kc_out = kKcO; o.slab_rows_out = Bp;
-        CHK(run_skinny(e, o));
-        CHK(run_finish(e, e->po.p, kKcO, w.post_ln, B, nullptr));
-        SkinnyArgs gu;
-        gu.X = e->dxn.p; gu.ldx = 576; gu.K = 576; gu.Wp = w.gateup.p; gu.K8p = w.gateup.KP / 8; gu.N = 3072; gu.Y = e->pg.p;
-        gu.ldy = 3072; gu.RB = RB; gu.kc_out = kKcGu; gu.slab_rows_out = Bp;
-        CHK(run_skinny(e, gu));
-        SkinnyArgs d;
-        d.X = e->pg.p; d.ldx = 3072; d.K = 1536; d.Wp = w.down.p; d.K8p = w.down.KP / 8; d.N = 576; d.Y = e->pd.p; d.ldy = 576;
-        d.RB = RB; d.pro = PRO_SWIGLU; d.kc_in = kKcGu; d.slab_rows = Bp; d.kc_out = kKcDown; d.slab_rows_out = Bp;
-        CHK(run_skinny(e, d));
+        const int kcd = l == 0 ? 0 : DEC_KC_DOWN;
+        DecArgs a = e->da;
+        a.inc_pos = l == 0 ? 1 : 0;     // the first kernel of a step advances the position word
+        { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 960.0, 576.0 * 960.0 * 4);
+          launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
+        { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
+          launch_dec_attn(e->da, kc, vc, kcd, s); }
+        { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
+          launch_dec_oproj(e->da, w.o16, s); }
+        { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
+          launch_dec_gateup(e->da, w.gateup_f.p, w.gateup_f.KP / 8, s); }
+        { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
+          launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
     }
-    CHK(run_lm_head(e, B, kKcDown, rec));
+    CHK(run_lm_head(e, B, DEC_KC_DOWN, rec));
     return 0;
 }
 
@@ -1079,7 +1094,7 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
     if (e->cur_pos + 1 > e->kv_Tmax) return fail("KV pages exhausted (reserve too small)");
     HIPCHK(hipSetDevice(e->device));
     const int B = e->cur_B;
-    launch_gather_rows(e->embed, 576, token_ids, B, 576, e->dx.p, 576, e->stream);
+    launch_dec_load_rows(e->da, B, e->embed, 576, token_ids, 0, e->stream);
     CHK(enqueue_decode_layers(e, B, nullptr));   // its first kernel advances the device position word
     e->cur_pos += 1;
     if (logits)
@@ -1220,6 +1235,22 @@ int mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms
     if (encode_ms) *encode_ms = e->phase_ms[0];
     if (prefill_ms) *prefill_ms = e->phase_ms[1];
     if (decode_ms) *decode_ms = e->phase_ms[2];
+    return 0;
+}
+// developer instrumentation (not part of the public header): s_memtime stamps of workgroup 0 of the decode kernels
+int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
+    if (!e) return fail("null engine");
+    static uint64_t* buf = nullptr;
+    HIPCHK(hipSetDevice(e->device));
+    if (on) {
+        if (!buf) HIPCHK(hipMalloc(&buf, 64 * sizeof(uint64_t)));
+        HIPCHK(hipMemset(buf, 0, 64 * sizeof(uint64_t)));
+        set_kernel_debug_buffer(buf);
+    } else {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (buf && host_out64) HIPCHK(hipMemcpy(host_out64, buf, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        set_kernel_debug_buffer(nullptr);
+    }
     return 0;
 }
 int mellow_set_graph(mellow_engine_t* e, int on) {

@@ -62,33 +62,51 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 
-// ---- skinny (decode) split-K GEMM: P[kc][32*RB][N] = X[32*RB][K-slice kc] * W^T -----------------------------
-enum { PRO_PLAIN = 0, PRO_SWIGLU = 2 };
-// split-K factors of the decode GEMMs (compile-time: slab sums are fully unrolled): K/8 = KC * 4 waves * KPW
-constexpr int SK_KC_QKV = 9, SK_KC_O = 9, SK_KC_GU = 3, SK_KC_DOWN = 16;
-struct SkinnyArgs {
-    const float* X = nullptr;   // PRO_PLAIN: row-major [rows][ldx]; PRO_SWIGLU: kc_in slabs [kc_in][slab_rows][ldx]
-    int64_t ldx = 0;
-    int K = 0;                  // logical K; K/8 must equal kc_out * 4 * {2,3,6,9,18}
-    const float* Wp = nullptr;
-    int K8p = 0;                // packed k8 stride = roundup(K,32)/8
-    int N = 0;                  // logical outputs (n-tiles = ceil(N/32)); multiple of 4
-    float* Y = nullptr;         // partial slabs [kc_out][slab_rows_out][ldy] (may be null when only candidates wanted)
-    int64_t ldy = 0;
-    int RB = 1;                 // row blocks of 32
-    int pro = PRO_PLAIN;
-    int kc_in = 1;              // PRO_SWIGLU: input slabs to sum
-    int slab_rows = 0;          // rows per input slab
-    int kc_out = 1;             // split-K factor = output slabs
-    int slab_rows_out = 0;      // rows per output slab
-    float* cand_val = nullptr;  // optional fused arg-max candidates [rows][n-tiles] (kc_out must be 1)
-    int32_t* cand_idx = nullptr;
+// ---- decode step (decode.hip) --------------------------------------------------------------------------------
+// split factors are compile-time so that partial-sum ("slab") loads are fully unrolled and issued together
+constexpr int DEC_KC_QKV = 9;    // qkv: 72 k-tiles = 9 chunks x 4 waves x 2
+constexpr int DEC_KC_DOWN = 8;   // down: 192 k-tiles = 8 chunks x 6 waves x 4
+constexpr int DEC_TS = 2;        // key splits of the decode attention, merged by the o_proj prologue
+struct DecArgs {
+    int rows = 0, RB = 0;          // padded batch rows (multiple of 32), row blocks
+    int Tmax = 0;
+    float eps = 1e-5f;
+    int32_t* d_pos = nullptr;      // device position word: index of the token being processed
+    int inc_pos = 0;               // qkv kernel of layer 0 advances it
+    const float* rope_cos = nullptr;
+    const float* rope_sin = nullptr;
+    // residual stream: "mid" = layer input base (embedding rows / previous layer's x_mid), row-major + F32-layout
+    float* xmidR = nullptr; float* xmidF = nullptr;
+    float* xnewR = nullptr;        // x after the previous down projection, materialised by the attention kernel
+    float* dslabR = nullptr; float* dslabF = nullptr;   // down split-K slabs [DEC_KC_DOWN][rows][576] / F32-layout
+    int64_t slabF_stride4 = 0;     // float4 elements between F-layout slabs
+    float* pq = nullptr;           // qkv split-K slabs [DEC_KC_QKV][rows][960]
+    float* attF16 = nullptr;       // attention partial outputs [DEC_TS][RB][36][2][64][4] (F16-layout)
+    float* att_m = nullptr; float* att_l = nullptr;     // [DEC_TS][9][rows]
+    float* ssq = nullptr;          // [rows][40] per-o_proj-tile sums of squares of x_mid
+    float* guF = nullptr;          // gate/up [RB][192][2][64][4] (F32-layout of the down projection)
+    float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
+    float* logits = nullptr;       // [rows][vocab] (may be null)
+    float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
-void launch_skinny(const SkinnyArgs& a, hipStream_t s);
-// x_out[r] = x_in[r] + sum_{s<kc} P[s][r]  (x_out may be null);  xn[r] = norm_w * (x_out[r] * rsqrt(mean^2+eps)) if norm_w
-// inc_word (may be null): a device int32 incremented by one (the decode position word, see engine.cpp)
-void launch_rows_finish(const float* x_in, const float* P, int kc, int64_t slab_stride, float* x_out,
-                        const float* norm_w, float eps, float* xn, int rows, int C, int32_t* inc_word, hipStream_t s);
+void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s);
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, hipStream_t s);
+void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s);
+void launch_dec_gateup(const DecArgs& a, const float* Wp_folded, int K8p, hipStream_t s);
+void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s);
+void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s);
+void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s);
+// per-row arg-max over the lm_head candidates; records at column (*d_pos - T0 + 1) when out_tokens != null, tracks
+// stop ids, and (write_x) gathers embed[token] as the next step's residual stream
+void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
+                       int32_t* out_tokens, int max_len, int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen,
+                       hipStream_t s);
+// residual stream <- rows of `in`: row_ids[b] (embedding gather) or, when row_ids == null, row b*T_last + T_last-1
+void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
+                          hipStream_t s);
+void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s);
+// developer instrumentation: device buffer of 64 uint64 slots stamped by workgroup 0 of the decode kernels (null = off)
+void set_kernel_debug_buffer(uint64_t* p);
 
 // ---- front-end ---------------------------------------------------------------------------------------
 void launch_reflect_pad(const float* wav, int n_clips, int64_t n_samples, float* out, int64_t padded_len, int pad,
@@ -132,28 +150,7 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 // causal GQA flash attention over the KV pages written by the QKV epilogue.  q [B*T][576]; o [B*T][576]
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
                               int Tmax, hipStream_t s);
-// one decode step: qkv split-K slabs [kc][rows][960] (q|k|v, no RoPE yet) at position *d_pos; sums the slabs,
-// applies RoPE, appends K/V to the pages, attends over pos+1 keys.  o [32*RB][576]
-void launch_decode_attention(const float* qkv_parts, int kc, int64_t slab_stride, float* k_cache, float* v_cache,
-                             const float* rope_cos, const float* rope_sin, const int32_t* d_pos, float* o, int B,
-                             int Tmax, hipStream_t s);
-
-// ---- sampling / bookkeeping ------------------------------------------------------------------------------
+// ---- misc ------------------------------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);
-// per-row arg-max over the lm_head's per-tile candidates; optionally (out_tokens != null) records the token at
-// column (*d_pos - T0 + 1) and tracks stop ids; optionally (x != null) gathers embed[token] into x[b]
-void launch_argmax_cand(const float* cand_val, const int32_t* cand_idx, int B, int n_tiles, int32_t* tokens,
-                        const float* embed, int H, float* x, int32_t* out_tokens, int max_len, const int32_t* d_pos,
-                        int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen, hipStream_t s);
-// x[b] = embed[tokens[b]] (x may be null); records tokens[b] into out_tokens[b][*d_step] (out_tokens may be null),
-// updates seen_stop / n_seen, then advances *d_step (when recording)
-void launch_embed_and_record(const float* embed, const int32_t* tokens, int B, int H, float* x, int32_t* out_tokens,
-                             int max_len, int32_t* d_step, int stop_id, int32_t* seen_stop, int32_t* n_seen,
-                             hipStream_t s);
-void launch_advance(int32_t* p, hipStream_t s);
-void launch_gather_rows(const float* in, int64_t ld_in, const int32_t* rows, int n, int C, float* out, int64_t ld_out,
-                        hipStream_t s);
-// rows b*T + (T-1) of x -> out[b]
-void launch_take_last(const float* x, int B, int T, int C, float* out, hipStream_t s);
 
 }  // namespace mellow

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): s_memtime phase stamps of workgroup 0 of the decode kernels."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mellow_amd import synth  # noqa: E402
+from mellow_amd.engine import Engine  # noqa: E402
+
+eng = Engine(device=0, max_positions=1024)
+eng.load_state_dict(synth.make_state_dict(0))
+B = 32
+a1, a2, ids = synth.make_batch(B)
+a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
+eng.generate(a1d, a2d, idsd, max_len=8, stop_id=0, ignore_stop=True)
+fn = eng.lib.mellow_dev_kdebug
+fn.restype = C.c_int
+fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+eng.set_graph(False)
+assert fn(eng.h, 1, None) == 0
+eng.generate(a1d, a2d, idsd, max_len=8, stop_id=0, ignore_stop=True)
+out = (C.c_uint64 * 64)()
+assert fn(eng.h, 0, out) == 0
+v = np.asarray(list(out), dtype=np.int64).reshape(8, 8)
+names = {0: "dec_qkv      [start, issued, mfma done, reduced(sync), pre-store]",
+         1: "dec_attn     [start, issued, sync1(data+stats), sync2(rope/lds), kv loop done, sync3, end]",
+         2: "dec_oproj    [start, issued, merge+mfma done, sync, end]",
+         3: "dec_gateup   [start, issued, mfma done, sync, end]",
+         4: "dec_down     [start, issued, mfma done, sync, end]",
+         5: "dec_lm_head  [start, issued, mfma done, sync, -]"}
+for k, nm in names.items():
+    row = v[k]
+    base = row[0]
+    print(nm)
+    print("   cycles since start:", [int(x - base) if x else None for x in row[:7]])
