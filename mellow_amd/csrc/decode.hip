@@ -52,59 +52,54 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K1  qkv projection, split-K.  grid (30 n-tiles, DEC_KC_QKV, RB), 4 waves, 2 k-tiles per wave.
+// K1  qkv projection, split-K.  grid (30 n-tiles, DEC_KC_QKV, RB) = 240 workgroups, 3 waves x 3 k-tiles (+1 epilogue wave).
 //     X = baseF + sum_{s<KCD} dslabF[s]  (residual stream, un-normalised; norm weight folded into W)
 //     out: pq[kc][row][960] row-major slabs (consumer = attention, row-parallel)
 // ----------------------------------------------------------------------------------------------------
 template <int KCD>
 __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
-    constexpr int KPW = 72 / (DEC_KC_QKV * 4);   // 2
-    const int k8_0 = (kc * 4 + wave) * KPW;
+    constexpr int KPW = 72 / (DEC_KC_QKV * 3);   // 3 k-tiles per wave, waves 0..2 compute, wave 3 only helps the epilogue
     // the first kernel of a step advances the position word (nothing of the previous step reads it any more)
     if (a.inc_pos && tid == 0 && nt == 0 && kc == 0 && rb == 0) *a.d_pos = *a.d_pos + 1;
-    const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
-    kstamp(0, 0, dbg);
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
-    const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
-    const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
-    float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
+    if (wave < 3) {
+        const int k8_0 = (kc * 3 + wave) * KPW;
+        const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+        const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        w[i] = wp[i * 64];
-        x[i] = xb[i * 64];
+        for (int i = 0; i < KPW; ++i) {
+            w[i] = wp[i * 64];
+            x[i] = xb[i * 64];
 #pragma unroll
-        for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
+            for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            float4 xv = x[i];
+#pragma unroll
+            for (int s = 0; s < KCD; ++s) xv = f4add(xv, sl[i][s]);
+            acc = mfma4(acc, w[i], xv);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     }
-    __builtin_amdgcn_sched_barrier(0);
-    kstamp(0, 1, dbg);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        float4 xv = x[i];
-#pragma unroll
-        for (int s = 0; s < KCD; ++s) xv = f4add(xv, sl[i][s]);
-        acc = mfma4(acc, w[i], xv);
-    }
-    kstamp(0, 2, dbg && acc[0] == acc[0]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    kstamp(0, 3, dbg);
     const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 4 * gq + j;
-        v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) +
-               (red[(2 * 16 + r) * 64 + mm + 32 * hh] + red[(3 * 16 + r) * 64 + mm + 32 * hh]);
+        v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) + red[(2 * 16 + r) * 64 + mm + 32 * hh];
     }
     const int n = nt * 32 + 8 * gq + 4 * hh;
-    kstamp(0, 4, dbg);
     if (n < 960)
         *reinterpret_cast<float4*>(a.pq + ((int64_t)kc * a.rows + rb * 32 + mm) * 960 + n) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -323,26 +318,27 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K3  o_proj with complete output.  grid (36 n16-tiles, RB), 16 waves; v_mfma_f32_16x16x4_f32, W in P16-layout.
-//     X = merge of the DEC_TS attention splits (coalesced F16 loads);  x_mid = x_new + X Wo^T
-//     writes x_mid row-major + F32-layout (gate/up operand) + per-tile sum of squares (down's RMS scale)
+// K3  o_proj with complete output.  grid (36 n16-tiles, 2 row halves x RB), 16 waves; v_mfma_f32_16x16x4_f32,
+//     W in P16-layout.  A workgroup owns 16 rows x 16 columns and the whole K = 576 (one MFMA tile), so its
+//     output is complete: x_mid = x_new + merge(attention splits) Wo^T.  Splitting the 32 batch rows into two
+//     halves doubles the workgroups (72) and halves the activation bytes each CU has to pull.
+//     writes x_mid row-major + F32-layout (next layer's qkv) + F16-layout (gate/up) + per-tile sum of squares
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
-    __shared__ __attribute__((aligned(16))) float red[16 * 8 * 64];   // 32 KiB: [wave][acc reg 0..7][lane]
+    __shared__ __attribute__((aligned(16))) float red[16 * 4 * 64];   // 16 KiB: [wave][acc reg][lane]
     constexpr int TPW = 3, K16 = 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x, rb = blockIdx.y;
+    const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
     const int ml = lane & 15;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + (int64_t)nt * K16 * 64 + lane;
-    // epilogue operand issued up front: thread (m, nq) of the 32 x 16 tile owns 4 consecutive columns
-    const int em = (tid >> 2) & 31, enq = tid & 3;
-    const int64_t erow = (int64_t)rb * 32 + em;
+    // epilogue operand issued up front: thread (m, nq) of the 16 x 16 tile owns 4 consecutive columns
+    const int em = (tid >> 2) & 15, enq = tid & 3;
+    const int64_t erow = (int64_t)rb * 32 + mh * 16 + em;
     const float4 xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
-    const bool dbg = tid == 0 && nt == 0 && rb == 0;
-    kstamp(2, 0, dbg);
 
-    float4 w[TPW], os[TPW][2][DEC_TS];
-    float ms[TPW][2][DEC_TS], ls[TPW][2][DEC_TS];
+    float4 w[TPW], os[TPW][DEC_TS];
+    float ms[TPW][DEC_TS], ls[TPW][DEC_TS];
+    const int64_t row = (int64_t)rb * 32 + mh * 16 + ml;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = wave + 16 * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
@@ -350,76 +346,56 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
         if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int64_t row = (int64_t)rb * 32 + ml + 16 * half;
-#pragma unroll
-            for (int s = 0; s < DEC_TS; ++s) {
-                ms[i][half][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
-                ls[i][half][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
-                os[i][half][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + half) * 64 + lane];
-            }
+        for (int s = 0; s < DEC_TS; ++s) {
+            ms[i][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
+            ls[i][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
+            os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    kstamp(2, 1, dbg);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        float4 xh[2];
+        // merge the key splits: x = sum_s f_s o_s / sum_s f_s l_s, f_s = exp(m_s - max m)
+        float M = ms[i][0];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // merge the key splits: x = sum_s f_s o_s / sum_s f_s l_s, f_s = exp(m_s - max m)
-            float M = ms[i][half][0];
+        for (int s = 1; s < DEC_TS; ++s) M = fmaxf(M, ms[i][s]);
+        float L = 0.f;
+        float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int s = 1; s < DEC_TS; ++s) M = fmaxf(M, ms[i][half][s]);
-            float L = 0.f;
-            float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int s = 0; s < DEC_TS; ++s) {
-                const float f = expf(ms[i][half][s] - M);
-                L += ls[i][half][s] * f;
-                O.x += os[i][half][s].x * f; O.y += os[i][half][s].y * f;
-                O.z += os[i][half][s].z * f; O.w += os[i][half][s].w * f;
-            }
-            const float inv = 1.0f / L;
-            xh[half] = make_float4(O.x * inv, O.y * inv, O.z * inv, O.w * inv);
+        for (int s = 0; s < DEC_TS; ++s) {
+            const float f = expf(ms[i][s] - M);
+            L += ls[i][s] * f;
+            O.x += os[i][s].x * f; O.y += os[i][s].y * f; O.z += os[i][s].z * f; O.w += os[i][s].w * f;
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, xh[0].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, xh[1].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, xh[0].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, xh[1].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, xh[0].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, xh[1].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, xh[0].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, xh[1].w, acc1, 0, 0, 0);
+        const float inv = 1.0f / L;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, O.x * inv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, O.y * inv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, O.z * inv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, O.w * inv, acc, 0, 0, 0);
     }
-    kstamp(2, 2, dbg && acc0[0] == acc0[0]);
-    // D[i = n_local = 4*(lane>>4) + r][j = m_local = lane&15]; acc0 rows 0..15, acc1 rows 16..31
+    // D[i = n_local = 4*(lane>>4) + r][j = m_local = lane&15]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        red[(wave * 8 + r) * 64 + lane] = acc0[r];
-        red[(wave * 8 + 4 + r) * 64 + lane] = acc1[r];
-    }
+    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    kstamp(2, 3, dbg);
-    if (tid < 128) {
-        // columns n = 4*enq + r live in registers r = 0..3 of lane (em&15) + 16*enq, accumulator (em>>4)
-        const int src_lane = (em & 15) + 16 * enq, rbase = (em >> 4) * 4;
+    if (tid < 64) {
+        // columns n = 4*enq + r live in registers r = 0..3 of lane em + 16*enq
+        const int src_lane = em + 16 * enq;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int wv = 0; wv < 16; ++wv)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += red[(wv * 8 + rbase + r) * 64 + src_lane];
+            for (int r = 0; r < 4; ++r) v[r] += red[(wv * 4 + r) * 64 + src_lane];
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
         const int k = nt * 16 + enq * 4;
         *reinterpret_cast<float4*>(a.xmidR + erow * 576 + k) = y;
-        reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, em, k)] = y;
+        reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, mh * 16 + em, k)] = y;
+        reinterpret_cast<float4*>(a.xmidF16)[(((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq] = y;
         float ss = f4ssq(y);
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
+        ss += dpp_mov<0xB1>(ss);             // sum over the quad (the 4 column groups of one row)
+        ss += dpp_mov<0x4E>(ss);
         if (enq == 0) a.ssq[erow * 40 + nt] = ss;
     }
-    kstamp(2, 4, dbg);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -498,6 +474,63 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
             a.cand_val[o] = best;
             a.cand_idx[o] = idx;
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K4b gate/up projection on 16-row weight tiles.  grid (192 n16-tiles, RB), 4 waves x 9 k16-tiles,
+//     v_mfma_f32_16x16x4_f32; W = folded gate/up in P16-layout with (gate, up) interleaved at 16 rows:
+//     tile 2j = gate[16j..16j+15], tile 2j+1 = up[16j..16j+15].  X = x_mid in F16-layout.
+//     192 workgroups x (36 KB of W + 72 KB of X); the dependent MFMA chain per wave is 72 x 32 cycles.
+//     writes g/u in the down projection's F32-layout guF[rb][hidden/8][g|u][lane][4].
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 8 * 64];   // 8 KiB
+    constexpr int TPW = 9, K16 = 36;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x, rb = blockIdx.y;
+    const int t0 = wave * TPW;
+    const float4* wp = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * K16 + t0) * 64 + lane;
+    const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
+    float4 w[TPW], x0[TPW], x1[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        w[i] = wp[i * 64];
+        x0[i] = xp[(i * 2) * 64];
+        x1[i] = xp[(i * 2 + 1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x0[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x1[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x0[i].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x1[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x0[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x1[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x0[i].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x1[i].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(wave * 8 + r) * 64 + lane] = acc0[r];
+        red[(wave * 8 + 4 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        // thread (m = 0..31, nq = 0..3): columns 4*nq + r are registers r of lane (m&15) + 16*nq, accumulator m>>4
+        const int m = tid >> 2, nq = tid & 3;
+        const int src_lane = (m & 15) + 16 * nq, rbase = (m >> 4) * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            v[r] = (red[(0 * 8 + rbase + r) * 64 + src_lane] + red[(1 * 8 + rbase + r) * 64 + src_lane]) +
+                   (red[(2 * 8 + rbase + r) * 64 + src_lane] + red[(3 * 8 + rbase + r) * 64 + src_lane]);
+        // hidden unit = 16*(nt>>1) + 4*nq + r  ->  down k-tile kd = 2*(nt>>1) + (nq>>1), lane' = m + 32*(nq&1)
+        const int is_up = nt & 1, kd = 2 * (nt >> 1) + (nq >> 1);
+        reinterpret_cast<float4*>(a.guF)[(((int64_t)rb * 192 + kd) * 2 + is_up) * 64 + m + 32 * (nq & 1)] =
+            make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -670,10 +703,10 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, 
     else hipLaunchKernelGGL((dec_attn_kernel<DEC_KC_DOWN>), grid, dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
 }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    hipLaunchKernelGGL(dec_oproj_kernel, dim3(36, a.RB), dim3(1024), 0, s, a, Wp16);
+    hipLaunchKernelGGL(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(1024), 0, s, a, Wp16);
 }
-void launch_dec_gateup(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
-    hipLaunchKernelGGL((dec_fullk_kernel<OUT_GU>), dim3(96, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xmidF, 3072);
+void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s) {
+    hipLaunchKernelGGL(dec_gateup16_kernel, dim3(192, a.RB), dim3(256), 0, s, a, Wp16);
 }
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
     hipLaunchKernelGGL(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(384), 0, s, a, Wp, K8p);

@@ -96,6 +96,7 @@ struct LMLayerW {
     Packed qkv, o, gateup, down;       // prefill (plain weights, P-layout); `down` is also the decode operand
     Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
     float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
+    float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, (gate, up) interleaved at 16 rows
     float *in_ln, *post_ln;
 };
 
@@ -112,6 +113,8 @@ struct mellow_engine {
     bool finalized = false;
     std::map<std::string, HostTensor> host;   // until finalize
     std::vector<void*> allocs;                // everything hipMalloc'd for weights
+    char* arena = nullptr;                    // one big allocation the weights are carved from
+    size_t arena_size = 0, arena_used = 0;
 
     // encoder weights
     Packed dft, mel;
@@ -177,9 +180,32 @@ static int ensure(mellow_engine* e, mellow_engine::Buf& b, size_t floats) {
     b.cap = floats;
     return 0;
 }
+// All weights are carved out of ONE large device allocation: a decode step touches every weight byte exactly once
+// (538 MB), and hundreds of small hipMallocs leave the address translation with small page fragments.
 static int dev_alloc(mellow_engine* e, float** out, size_t floats) {
+    const size_t bytes = (floats * sizeof(float) + 4095) / 4096 * 4096;
+    if (!e->arena) {
+        size_t want = (size_t)3400 << 20;
+        const char* env = getenv("MELLOW_ARENA_MB");
+        if (env) want = (size_t)atol(env) << 20;
+        if (want) {
+            void* p = nullptr;
+            if (hipMalloc(&p, want) == hipSuccess) {
+                e->arena = reinterpret_cast<char*>(p);
+                e->arena_size = want;
+                e->allocs.push_back(p);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    if (e->arena && e->arena_used + bytes <= e->arena_size) {
+        *out = reinterpret_cast<float*>(e->arena + e->arena_used);
+        e->arena_used += bytes;
+        return 0;
+    }
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, floats * sizeof(float)));
+    HIPCHK(hipMalloc(&p, bytes));
     e->allocs.push_back(p);
     *out = reinterpret_cast<float*>(p);
     return 0;
@@ -652,7 +678,14 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                     gf[(size_t)n * H + kk] = g->f()[(size_t)n * H + kk] * l2->f()[kk];
                     uf[(size_t)n * H + kk] = u->f()[(size_t)n * H + kk] * l2->f()[kk];
                 }
-            CHK(make_packed(e, gf.data(), uf.data(), I, H, &w.gateup_f));
+            {
+                std::vector<float> il((size_t)2 * I * H);     // rows: gate[16j..16j+15], up[16j..16j+15], j = 0..95
+                for (int j = 0; j < I / 16; ++j) {
+                    memcpy(il.data() + (size_t)(2 * j) * 16 * H, gf.data() + (size_t)j * 16 * H, (size_t)16 * H * 4);
+                    memcpy(il.data() + (size_t)(2 * j + 1) * 16 * H, uf.data() + (size_t)j * 16 * H, (size_t)16 * H * 4);
+                }
+                CHK(make_packed16(e, il.data(), 2 * I, H, &w.gu16));
+            }
             CHK(make_packed16(e, get(e, p + "self_attn.o_proj.weight")->f(), H, 576, &w.o16));
         }
         e->layers.push_back(w);
@@ -884,7 +917,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         const size_t o_dslabR = take(DEC_KC_DOWN * n_x), o_dslabF = take(DEC_KC_DOWN * n_x);
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
         const size_t o_att = take((size_t)DEC_TS * n_x), o_am = take((size_t)DEC_TS * 9 * Bp), o_al = take((size_t)DEC_TS * 9 * Bp);
-        const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 2 * 256);
+        const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 2 * 256), o_xmidF16 = take(n_x);
         const bool fresh = e->dec.cap < off;
         CHK(ensure(e, e->dec, off));
         CHK(ensure(e, e->dlogits, (size_t)Bp * V));
@@ -900,7 +933,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidR = p + o_xmidR; a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
         a.dslabR = p + o_dslabR; a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4);
-        a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu;
+        a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu; a.xmidF16 = p + o_xmidF16;
         a.logits = e->dlogits.p; a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * (V / 32));
     }
     if (Bp > 1024) return fail("batch too large for the decode state block");
@@ -999,7 +1032,7 @@ static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec)
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
           launch_dec_oproj(e->da, w.o16, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
-          launch_dec_gateup(e->da, w.gateup_f.p, w.gateup_f.KP / 8, s); }
+          launch_dec_gateup(e->da, w.gu16, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
           launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
     }

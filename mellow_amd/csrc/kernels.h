@@ -64,7 +64,7 @@ double gemm_flops(const GemmArgs& a);
 
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------
 // split factors are compile-time so that partial-sum ("slab") loads are fully unrolled and issued together
-constexpr int DEC_KC_QKV = 9;    // qkv: 72 k-tiles = 9 chunks x 4 waves x 2
+constexpr int DEC_KC_QKV = 8;    // qkv: 72 k-tiles = 8 chunks x 3 waves x 3  (30 x 8 = 240 workgroups <= 256 CUs)
 constexpr int DEC_KC_DOWN = 8;   // down: 192 k-tiles = 8 chunks x 6 waves x 4
 constexpr int DEC_TS = 2;        // key splits of the decode attention, merged by the o_proj prologue
 struct DecArgs {
@@ -84,6 +84,7 @@ struct DecArgs {
     float* attF16 = nullptr;       // attention partial outputs [DEC_TS][RB][36][2][64][4] (F16-layout)
     float* att_m = nullptr; float* att_l = nullptr;     // [DEC_TS][9][rows]
     float* ssq = nullptr;          // [rows][40] per-o_proj-tile sums of squares of x_mid
+    float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // gate/up [RB][192][2][64][4] (F32-layout of the down projection)
     float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
     float* logits = nullptr;       // [rows][vocab] (may be null)
@@ -92,7 +93,7 @@ struct DecArgs {
 void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s);
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, hipStream_t s);
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s);
-void launch_dec_gateup(const DecArgs& a, const float* Wp_folded, int K8p, hipStream_t s);
+void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s);
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s);
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s);
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s);

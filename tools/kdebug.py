@@ -37,3 +37,6 @@ for k, nm in names.items():
     base = row[0]
     print(nm)
     print("   cycles since start:", [int(x - base) if x else None for x in row[:7]])
+
+r = v[6]
+print("qkv startup probe (cycles): entry->kernarg", int(r[1]-r[0]), " kernarg->issued", int(r[2]-r[1]), " issued->first data", int(r[3]-r[2]))
