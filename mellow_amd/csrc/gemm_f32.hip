@@ -18,6 +18,8 @@
 //  * 4 waves per workgroup, 64x64 per wave (4 accumulators), block 128x128 or 256x64, BK = 32,
 //    double-buffered LDS with register prefetch (one barrier per k-tile).
 //  * XCD-aware block order: all n-blocks of an m-panel run on one XCD (A panel read once per L2).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -51,6 +53,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     const int nt0 = pn * NTB;
     const int K8 = g.K >> 3;
     const int KT = g.K >> 5;
+    // a wave whose 64 output columns are all beyond the weight's rows only helps with staging (frees the MFMA pipe)
+    const bool wave_active = (pn * BN + wn * 64) < g.Nw;
 
     // ---- per-thread load descriptors -------------------------------------------------------------
     const float* a_ptr[A_F4];
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
         for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][(int64_t)ktn * 4 * 64];
         const float4* Ac = As + cur * A_STAGE;
         const float4* Wc = Ws + cur * W_STAGE;
+        if (wave_active) {
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             const float4 a0 = Ac[(k8 * MT + 2 * wm) * 64 + lane];
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a1.w, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a0.w, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a1.w, acc[1][1], 0, 0, 0);
+        }
         }
         {
             float4* An = As + (cur ^ 1) * A_STAGE;
@@ -271,7 +277,9 @@ template <int EPI>
 static void launch_epi(const GemmArgs& a, hipStream_t s) {
     // pick the block shape that wastes fewer padded columns: 128x128 or 256x64
     const int w128 = (a.Nw + 127) / 128 * 128, w64 = (a.Nw + 63) / 64 * 64;
-    if (w64 < w128 && a.M >= 256) launch_cfg<4, 1, EPI>(a, s);
+    static const int force = getenv("MELLOW_GEMM_TILE") ? atoi(getenv("MELLOW_GEMM_TILE")) : 0;   // dev knob: 1 = always 128x128, 2 = old rule
+    const bool tall = force == 1 ? false : (force == 2 ? (w64 < w128 && a.M >= 256) : (a.Nw <= 64 && a.M >= 256));
+    if (tall) launch_cfg<4, 1, EPI>(a, s);
     else launch_cfg<2, 2, EPI>(a, s);
 }
 
