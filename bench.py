@@ -132,6 +132,14 @@ def main():
     eng.prof_enable(False)
 
     if rank == 0:
+        # HBM-side traffic of the dominant kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+        # in separate runs, gfx950 x2 read correction applied): it cannot be sampled from inside this process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
+                traffic = round(json.load(f)["traffic_bytes_per_launch"])
+        except Exception:
+            pass
         total = n_gpus * B * args.steps
         value = total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
@@ -151,7 +159,8 @@ def main():
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
             "roofline": {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)", "bound": "mfma",
                          "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (memory-side, PMC, profiles/r01_pmc_gemm_traffic.json)",
                          "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
                          "flops_per_step": g["flops"]},
             "path_roofline": {"t_roof_ms_per_step": round(t_roof * 1e3, 3),

@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
+    // XCD-aware tile order: xcd_remap gives every XCD (private L2) a contiguous range of logical ranks, m-major, so
+    // the n-blocks of one activation panel run together on one XCD.  (An n-major walk inside per-XCD panel groups was
+    // measured too: no fewer memory-side fetches, 2 % slower.)
     const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
     const int pm = L / p.gn, pn = L % p.gn;
     const int nt0 = pn * NTB;
