@@ -961,11 +961,13 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
     return 0;
 }
 
+static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, bool inc_pos);
 static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
     hipStream_t s = e->stream;
     const int M = B * T, Tmax = e->kv_Tmax;
+    const int NL = e->cfg.num_layers;
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
-    for (int l = 0; l < e->cfg.num_layers; ++l) {
+    for (int l = 0; l < NL; ++l) {
         const LMLayerW& w = e->layers[l];
         float* kc = e->kcache.p + kv_layer_floats(e) * l;
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
@@ -977,6 +979,9 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
             g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
             CHK(run_gemm(e, g));
         }
+        // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
+        // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
+        if (l == NL - 1) break;
         {
             // causal QK^T + PV: 4*64 flops per (query,key) pair per head
             ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
@@ -1000,14 +1005,16 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
             CHK(run_gemm(e, g));
         }
     }
+    // x now holds the input of the last layer.  Position word = index of the LAST prefix token: the decode kernels
+    // treat it as "the new token" (keys 0..T-2 from the pages, key T-1 recomputed and re-appended), and the first
+    // kernel of every later decode step advances it; the arg-max records its token at column (*d_pos - prefix_len + 1) = 0.
     { ProfScope ps(e, PF_MISC, 0, 0); launch_dec_load_rows(e->da, B, x, 576, nullptr, T, s); }
-    // position word = index of the LAST cached token; the first kernel of every decode step advances it, so the
-    // arg-max below records its token at column (*d_pos - prefix_len + 1) = 0
     e->cur_B = B;
     e->cur_pos = T;
     e->h_pos_word = T - 1;
     HIPCHK(hipMemcpyAsync(e->d_pos, &e->h_pos_word, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    CHK(run_lm_head(e, B, 0, rec));
+    CHK(enqueue_decode_layer_range(e, B, NL - 1, NL, false));
+    CHK(run_lm_head(e, B, DEC_KC_DOWN, rec));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1015,16 +1022,17 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
 // the 30 decode layers + head at position *d_pos (enqueue only; capture-safe).  5 launches per layer (decode.hip):
 //   qkv split-K | attention (RMS scale, RoPE, KV append, key-split flash decoding) | o_proj (merge + residual) |
 //   gate/up | down split-K (RMS scale, SwiGLU); the down slabs are summed by the next layer's qkv/attention.
-static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec) {
+static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArgs* rec);
+static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, bool inc_pos) {
     hipStream_t s = e->stream;
     const int Bp = e->da.rows;
-    for (int l = 0; l < e->cfg.num_layers; ++l) {
+    for (int l = l_begin; l < l_end; ++l) {
         const LMLayerW& w = e->layers[l];
         float* kc = e->kcache.p + kv_layer_floats(e) * l;
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
-        const int kcd = l == 0 ? 0 : DEC_KC_DOWN;
+        const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         DecArgs a = e->da;
-        a.inc_pos = l == 0 ? 1 : 0;     // the first kernel of a step advances the position word
+        a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // the first kernel of a step advances the position word
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 960.0, 576.0 * 960.0 * 4);
           launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
         { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
@@ -1036,6 +1044,10 @@ static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec)
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
           launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
     }
+    return 0;
+}
+static int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec) {
+    CHK(enqueue_decode_layer_range(e, B, 0, e->cfg.num_layers, true));
     CHK(run_lm_head(e, B, DEC_KC_DOWN, rec));
     return 0;
 }

@@ -30,14 +30,16 @@ struct GemmDev {
     int gm, gn;
 };
 
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int MT = BM / 32, NTB = BN / 32;      // 32-row tiles per block
-    constexpr int A_F4 = MT;                        // float4 per thread per k-tile (A)
-    constexpr int W_F4 = NTB;                       // float4 per thread per k-tile (W)
-    constexpr int A_STAGE = BM * 8;                 // float4 per stage
-    constexpr int W_STAGE = BN * 8;
+    constexpr int KS = BK / 8;                      // 8-wide k sub-tiles per k-tile
+    constexpr int CH = BK / 4;                      // float4 chunks per row per k-tile
+    constexpr int A_F4 = BM * CH / 256;             // float4 per thread per k-tile (A)
+    constexpr int W_F4 = BN * CH / 256;             // float4 per thread per k-tile (W)
+    constexpr int A_STAGE = BM * CH;                // float4 per stage
+    constexpr int W_STAGE = BN * CH;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* As = smem;                              // [2][A_STAGE]
     float4* Ws = smem + 2 * A_STAGE;                // [2][W_STAGE]
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     const int pm = L / p.gn, pn = L % p.gn;
     const int nt0 = pn * NTB;
     const int K8 = g.K >> 3;
-    const int KT = g.K >> 5;
+    const int KT = g.K / BK;
     // a wave whose 64 output columns are all beyond the weight's rows only helps with staging (frees the MFMA pipe)
     const bool wave_active = (pn * BN + wn * 64) < g.Nw;
 
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
 #pragma unroll
     for (int q = 0; q < A_F4; ++q) {
         const int idx = q * 256 + tid;
-        const int row = ((idx >> 6) << 3) + (idx & 7);
-        const int chunk = (idx >> 3) & 7;
+        // 8 consecutive lanes -> 8 rows (conflict-free 128 B LDS write), next lane bits -> the CH chunks of a row
+        const int row = (idx / (8 * CH)) * 8 + (idx & 7);
+        const int chunk = (idx >> 3) % CH;
         int m = pm * BM + row;
         m = m < g.M ? m : g.M - 1;
         int64_t off;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
 #pragma unroll
     for (int q = 0; q < W_F4; ++q) {
         const int idx = q * 256 + tid;
-        const int ln = idx & 63, k8 = (idx >> 6) & 3, ntl = idx >> 8;
+        const int ln = idx & 63, k8 = (idx >> 6) % KS, ntl = idx / (64 * KS);
         w_ptr[q] = reinterpret_cast<const float4*>(g.Wp) + ((int64_t)(nt0 + ntl) * K8 + k8) * 64 + ln;
         w_lds[q] = (k8 * NTB + ntl) * 64 + ln;
     }
@@ -110,14 +113,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
         // register arrays stay unconditional and are never demoted to scratch)
         const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q] + ktn * 32);
+        for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q] + ktn * BK);
 #pragma unroll
-        for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][(int64_t)ktn * 4 * 64];
+        for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][(int64_t)ktn * KS * 64];
         const float4* Ac = As + cur * A_STAGE;
         const float4* Wc = Ws + cur * W_STAGE;
         if (wave_active) {
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) {
+        for (int k8 = 0; k8 < KS; ++k8) {
             const float4 a0 = Ac[(k8 * MT + 2 * wm) * 64 + lane];
             const float4 a1 = Ac[(k8 * MT + 2 * wm + 1) * 64 + lane];
             const float4 w0 = Wc[(k8 * NTB + 2 * wn) * 64 + lane];
@@ -259,21 +262,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     }
 }
 
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int EPI, int BK>
 static void launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     GemmDev d;
     d.a = a;
     d.gm = (a.M + BM - 1) / BM;
     d.gn = (a.Nw + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI, BK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI, BK>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
 }
 
 template <int EPI>
@@ -282,8 +285,10 @@ static void launch_epi(const GemmArgs& a, hipStream_t s) {
     const int w128 = (a.Nw + 127) / 128 * 128, w64 = (a.Nw + 63) / 64 * 64;
     static const int force = getenv("MELLOW_GEMM_TILE") ? atoi(getenv("MELLOW_GEMM_TILE")) : 0;   // dev knob: 1 = always 128x128, 2 = old rule
     const bool tall = force == 1 ? false : (force == 2 ? (w64 < w128 && a.M >= 256) : (a.Nw <= 64 && a.M >= 256));
-    if (tall) launch_cfg<4, 1, EPI>(a, s);
-    else launch_cfg<2, 2, EPI>(a, s);
+    static const int bk = getenv("MELLOW_GEMM_BK") ? atoi(getenv("MELLOW_GEMM_BK")) : 32;   // dev knob
+    if (tall) launch_cfg<4, 1, EPI, 32>(a, s);
+    else if (bk == 16) launch_cfg<2, 2, EPI, 16>(a, s);
+    else launch_cfg<2, 2, EPI, 32>(a, s);
 }
 
 void launch_gemm(const GemmArgs& a, hipStream_t s) {
