@@ -244,3 +244,110 @@ def test_long_context_decode_matches_independent_prefill(engine, golden_dir):
     pre_logits = engine.lm_prefill(ext, reserve=2).cpu()
     _close(dec_logits, pre_logits, rel=0, atol=3e-3, name="decode@479 vs prefill of the extended sequence")
     assert dec_logits.argmax(-1).tolist() == pre_logits.argmax(-1).tolist()
+
+
+class _StubTokenizer:
+    """Deterministic stand-in for the SmolLM2 tokenizer (its files cannot be fetched offline): one id per
+    whitespace-separated word (stable hash into 17..49151), '!' is the pad id 1, '<|endoftext|>' is id 0."""
+    pad_id, eos_id = 1, 0
+
+    def _word(self, w):
+        if w == "<|endoftext|>":
+            return self.eos_id
+        h = 2166136261
+        for c in w.encode():
+            h = ((h ^ c) * 16777619) & 0xFFFFFFFF
+        return 17 + h % (49152 - 17)
+
+    def encode(self, text):
+        return [self._word(w) for w in text.split()]
+
+    def encode_plus(self, text, add_special_tokens=True, truncation=True, max_length=129, padding="max_length",
+                    return_tensors="pt"):
+        ids = self.encode(text)[:max_length]
+        mask = [1] * len(ids) + [0] * (max_length - len(ids))
+        ids = ids + [self.pad_id] * (max_length - len(ids))
+        return {"input_ids": torch.tensor([ids]), "attention_mask": torch.tensor([mask])}
+
+    def decode(self, ids):
+        return " ".join("<|endoftext|>" if int(i) == self.eos_id else f"t{int(i)}" for i in ids)
+
+
+def _write_wav16(path, x, sr):
+    import wave
+    pcm = (np.clip(x, -1, 1) * 32767.0).astype("<i2")
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(pcm.tobytes())
+
+
+def test_wrapper_end_to_end_from_wav_files(synth_sd, tmp_path):
+    """BASELINE config 1 shape (example.py flow): two wav files + a prompt through MellowWrapper.generate on the GPU
+    == the oracle driven with the SAME preprocessed arrays and ids (44.1 kHz file -> resample -> tile; 32 kHz file)."""
+    from mellow_amd import MellowWrapper
+    from mellow_amd.audio import load_audio_into_tensor
+    from oracle import mellow_oracle as O
+    rng = np.random.default_rng(5)
+    t1 = np.arange(int(3.3 * 44100)) / 44100.0
+    x1 = 0.3 * np.sin(2 * np.pi * 440 * t1) + 0.05 * rng.standard_normal(t1.size)
+    t2 = np.arange(int(10.0 * 32000)) / 32000.0
+    x2 = 0.2 * np.sin(2 * np.pi * 1250 * t2) * np.sin(2 * np.pi * 3 * t2) + 0.05 * rng.standard_normal(t2.size)
+    p1, p2 = tmp_path / "a.wav", tmp_path / "b.wav"
+    _write_wav16(p1, x1, 44100)
+    _write_wav16(p2, x2, 32000)
+    tok = _StubTokenizer()
+    m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=synth_sd, tokenizer=tok)
+    prompt = "what is the difference between the two audios"
+    examples = [[str(p1), str(p2), prompt], [str(p2), str(p1), "describe both"]]
+    got = m.generate(examples=examples, max_len=10, top_p=0.8, temperature=1.0)
+    assert isinstance(got, list) and len(got) == 2 and all(isinstance(s, str) for s in got)
+
+    a1 = torch.cat([load_audio_into_tensor(str(p), 10, 32000, True).reshape(1, -1) for p in (p1, p2)], 0)
+    a2 = torch.cat([load_audio_into_tensor(str(p), 10, 32000, True).reshape(1, -1) for p in (p2, p1)], 0)
+    ids = torch.cat([tok.encode_plus(p, max_length=spec.TEXT_LEN)["input_ids"] for p in (prompt, "describe both")], 0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        prefix = O.generate_prefix_inference(synth_sd, a1, a2, ids)
+        toks = O.generate_batch(synth_sd, O.LMParams(), prefix, 10, 0.8, 1.0, tok.eos_id)
+    want = [tok.decode(r).split("<|endoftext|>")[0] for r in np.asarray(toks)]
+    assert got == want
+    m.model.close()
+
+
+def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
+    """BASELINE configs[2] per-rank shape: top_p=0.8, temperature=1.0, max_len=300 (context 389..689).
+    The sampling arguments change nothing (reference wrapper.py:220-232 never removes the arg-max); the first tokens
+    are the reference golden ones; a long run extends a short one; other top_p / temperature values give the same ids."""
+    a1, a2, ids = synth.make_batch(4)
+    t300, lens, n, _ = engine.generate(a1, a2, ids, max_len=300, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
+    assert t300.shape == (4, 300) and n == 300 and (t300 >= 0).all() and (t300 < 49152).all()
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    assert np.array_equal(t300[:2, : g["tokens"].shape[1]], g["tokens"])
+    t64, *_ = engine.generate(a1, a2, ids, max_len=64, top_p=0.3, temperature=0.7, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t64, t300[:, :64])
+    # reference stop rule at this length: stop id := a token row 2 first produces late in the run
+    row = t300[2]
+    k = next(i for i in range(200, 300) if row[i] not in row[:i])
+    ts, lens, n, _ = engine.generate(a1[2:3], a2[2:3], ids[2:3], max_len=300, stop_id=int(row[k]))
+    assert int(lens[0]) == k and n >= k + 1 and np.array_equal(ts[0, : k + 1], row[: k + 1])
+
+
+def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
+    """BASELINE configs[3] shape at reduced batch: 2 x 30 s clips (7 encoder crops per clip), max_len=128.
+    Rows are batch-independent (exact), the prefix equals the oracle's, and the tokens extend the oracle's first steps."""
+    from oracle import mellow_oracle as O
+    B, L = 6, 128
+    a1, a2, ids = synth.make_batch(B, n_samples=30 * spec.SAMPLE_RATE)
+    t, lens, n, _ = engine.generate(a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
+    assert t.shape == (B, L) and n == L
+    t1, *_ = engine.generate(a1[4:5], a2[4:5], ids[4:5], max_len=L, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t1[0], t[4])
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        prefix = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1[:1]), torch.from_numpy(a2[:1]),
+                                             torch.from_numpy(ids[:1]))
+        want = O.generate_batch(synth_sd, O.LMParams(), prefix, 4, 0.8, 1.0, -1)
+    _close(engine.prefix(a1[:1], a2[:1], ids[:1]), prefix, name="30 s prefix")
+    assert np.array_equal(t[0, :4], np.asarray(want)[0])
