@@ -59,11 +59,20 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 template <int KCD>
 __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
     __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+    __shared__ float ssq_s[3 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
     constexpr int KPW = 72 / (DEC_KC_QKV * 3);   // 3 k-tiles per wave, waves 0..2 compute, wave 3 only helps the epilogue
-    // the first kernel of a step advances the position word (nothing of the previous step reads it any more)
-    if (a.inc_pos && tid == 0 && nt == 0 && kc == 0 && rb == 0) *a.d_pos = *a.d_pos + 1;
+    // The first kernel of a step (a.first): advance the position word (nothing of the previous step reads it any more)
+    // and stage this position's RoPE row at a fixed address, so that no attention kernel of the step has to chase
+    // pos -> table row (two dependent round trips).  One half-wave: the loads of *d_pos precede the store in program order.
+    if (a.first && nt == 29 && kc == 0 && rb == 0 && tid < 32) {
+        const int p = *a.d_pos + a.inc_pos;
+        const float c = a.rope_cos[(int64_t)p * 32 + tid], sn = a.rope_sin[(int64_t)p * 32 + tid];
+        a.rope_cur[tid] = c;
+        a.rope_cur[32 + tid] = sn;
+        if (tid == 0 && a.inc_pos) *a.d_pos = p;
+    }
     if (wave < 3) {
         const int k8_0 = (kc * 3 + wave) * KPW;
         const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
@@ -81,17 +90,30 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float ssp = 0.f;
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
             float4 xv = x[i];
 #pragma unroll
             for (int s = 0; s < KCD; ++s) xv = f4add(xv, sl[i][s]);
             acc = mfma4(acc, w[i], xv);
+            // side jobs of two n-tiles (the workgroups of one k-chunk see every row of x_new on these 72 columns):
+            //   nt == 0: partial sum of squares per row (the attention's RMS statistic)
+            //   nt == 1: x_new row-major (the o_proj's residual operand)
+            if (nt == 0) ssp += f4ssq(xv);
+            if (nt == 1)
+                *reinterpret_cast<float4*>(a.xnewR + ((int64_t)rb * 32 + (lane & 31)) * 576 + (k8_0 + i) * 8 + (lane >> 5) * 4) = xv;
+        }
+        if (nt == 0) {
+            ssp = half_sum(ssp);                 // the two k-halves of a row sit in lanes m and m + 32
+            if (lane < 32) ssq_s[wave * 32 + lane] = ssp;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     }
     __syncthreads();
+    if (nt == 0 && tid < 32)
+        a.ssq1[((int64_t)rb * 32 + tid) * DEC_KC_QKV + kc] = (ssq_s[tid] + ssq_s[32 + tid]) + ssq_s[64 + tid];
     const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
     float v[4];
 #pragma unroll
@@ -106,21 +128,19 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
 
 // ----------------------------------------------------------------------------------------------------
 // K2  attention (flash decoding).  grid (3 kv heads, rows, DEC_TS key splits), 8 waves.
-//     x_new[b] = base[b] + sum down slabs  ->  r1 (RMS scale);  q,k,v = r1 * sum_kc pq slabs;  RoPE; KV append;
+//     r1 = RMS scale of x_new from the qkv kernel's per-chunk sums;  q,k,v = r1 * sum_kc pq slabs;  RoPE; KV append;
 //     per-wave online softmax over an interleaved set of 4-key groups; partial (m, l, o) per split.
-//     Workgroup (g=0, split=0) also materialises x_new (row-major) for the o_proj residual.
+//     Split sp owns key groups [sp*gs, (sp+1)*gs) (the last split: everything from sp*gs on, plus the new key).
 // ----------------------------------------------------------------------------------------------------
 constexpr int DA_WAVES = 8;
 constexpr int DA_G = 7;          // 4-key groups in flight per wave: one chunk covers 2*8*7*4 = 448 keys
 
-template <int KCD>
 __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
                                                                   float* __restrict__ v_cache) {
     __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
     __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
     __shared__ __attribute__((aligned(16))) float ored[DA_WAVES * 3 * 64];
     __shared__ float mred[DA_WAVES * 3], lred[DA_WAVES * 3];
-    __shared__ float ssq[DA_WAVES];
     __shared__ float snew_s[3];
 
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
@@ -130,7 +150,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
     const int sub = lane >> 4, quad = lane & 15;   // lane -> (key sub, dim quad): a wave instruction = 4 keys x 64 dims
 
-    // ===== round trip 1 (independent, straight-line): position word, residual row (+slabs), qkv slabs =====
+    // ===== ONE round trip, every load independent and straight-line: position word, RMS partials, qkv slabs,
+    //       the staged RoPE row and the first chunk of K/V (key ranges of the splits are fixed per launch, a.gs,
+    //       so their addresses do not wait for the position; keys >= pos are masked after the loads land) =====
     const bool dbg = tid == 0 && g == 0 && b == 0 && sp == 0;
     kstamp(1, 0, dbg);
     const int pos = *a.d_pos;        // keys 0..pos-1 are cached; the new key is key `pos`
@@ -141,50 +163,35 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const int col1 = tid < 128 ? (hsel < 3 ? (3 * g + hsel) * 64 : 576 + g * 64) + i : 768 + g * 64 + ((tid - 128) & 63);
     const int col2 = tid < 128 ? col1 + 32 : col1;
     const float* prow = a.pq + (int64_t)b * 960;
-    float a1[DEC_KC_QKV], a2[DEC_KC_QKV];
+    float a1[DEC_KC_QKV], a2[DEC_KC_QKV], sq[DEC_KC_QKV];
 #pragma unroll
     for (int s = 0; s < DEC_KC_QKV; ++s) {
         a1[s] = prow[(int64_t)s * a.rows * 960 + col1];
         a2[s] = prow[(int64_t)s * a.rows * 960 + col2];
+        sq[s] = a.ssq1[(int64_t)b * DEC_KC_QKV + s];
     }
-    const int xi = tid < 144 ? tid : 0;
-    float4 xv = reinterpret_cast<const float4*>(a.xmidR + (int64_t)b * 576)[xi];
-    float4 xs[KCD > 0 ? KCD : 1];
-#pragma unroll
-    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabR + ((int64_t)s * a.rows + b) * 576)[xi];
-
-    // ===== round trip 2 (needs only pos): RoPE table row, first chunk of K/V =====
-    const float c = a.rope_cos[(int64_t)pos * 32 + i], sn = a.rope_sin[(int64_t)pos * 32 + i];
-    const int ngroups = (pos + 3) >> 2;                       // groups of 4 cached keys
-    const int gper = (ngroups + DEC_TS - 1) / DEC_TS;         // groups per split
-    const int gbeg = sp * gper, gend = min(ngroups, gbeg + gper);
+    const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
+    const int gbeg = sp * a.gs;                                   // groups of 4 keys
+    const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + a.gs;
     float4 k4[DA_G], v4[DA_G];
 #pragma unroll
     for (int u = 0; u < DA_G; ++u) {
         const int gi = gbeg + wave + u * DA_WAVES;
-        const int t = gi * 4 + sub;
-        const int tc = (gi < gend && t < pos) ? t : pos - 1;   // pos >= 1 always (a prefix precedes)
+        const int tc = min(gi * 4 + sub, Tmax - 1);               // inside the page; validity is decided later
         k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
         v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
     }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 1, dbg);
 
-    // ---- x_new row, its RMS statistic, materialisation ----
-#pragma unroll
-    for (int s = 0; s < KCD; ++s) xv = f4add(xv, xs[s]);
-    {
-        float ss = tid < 144 ? f4ssq(xv) : 0.f;
-        ss = wave_sum(ss);
-        if (lane == 0) ssq[wave] = ss;
-    }
-    if (g == 0 && sp == 0 && tid < 144) reinterpret_cast<float4*>(a.xnewR + (int64_t)b * 576)[tid] = xv;
+    const int ngroups = (pos + 3) >> 2;                           // groups of 4 cached keys
+    const int gend = min(ngroups, gend_fixed);
     float x1 = a1[0], x2 = a2[0];
 #pragma unroll
     for (int s = 1; s < DEC_KC_QKV; ++s) { x1 += a1[s]; x2 += a2[s]; }
-    __syncthreads();
-    kstamp(1, 2, dbg);
-    const float rscale = 1.0f / sqrtf((ssq[0] + ssq[1] + ssq[2]) / 576.0f + a.eps);   // waves 0..2 hold the 144 float4
+    static_assert(DEC_KC_QKV == 8, "fixed summation tree below");
+    const float ssum = ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
+    const float rscale = 1.0f / sqrtf(ssum / 576.0f + a.eps);
     x1 *= rscale; x2 *= rscale;
     if (tid < 128) {
         const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sn));
@@ -221,8 +228,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 #pragma unroll
             for (int u = 0; u < DA_G; ++u) {
                 const int gi = g0 + u * DA_WAVES;
-                const int t = gi * 4 + sub;
-                const int tc = (gi < gend && t < pos) ? t : pos - 1;
+                const int tc = min(gi * 4 + sub, Tmax - 1);
                 k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
                 v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
             }
@@ -388,7 +394,6 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
             for (int r = 0; r < 4; ++r) v[r] += red[(wv * 4 + r) * 64 + src_lane];
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
         const int k = nt * 16 + enq * 4;
-        *reinterpret_cast<float4*>(a.xmidR + erow * 576 + k) = y;
         reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, mh * 16 + em, k)] = y;
         reinterpret_cast<float4*>(a.xmidF16)[(((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq] = y;
         float ss = f4ssq(y);
@@ -594,7 +599,6 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
         const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(a.dslabR + ((int64_t)kc * a.rows + rb * 32 + mm) * 576 + n) = o;
         reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
     }
     kstamp(4, 4, dbg);
@@ -609,10 +613,11 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, co
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int xi = tid < 144 ? tid : 0;
-    float4 v = reinterpret_cast<const float4*>(a.xmidR + (int64_t)b * 576)[xi];
+    const int64_t fi = f32_idx(b >> 5, 72, b & 31, xi * 4);
+    float4 v = reinterpret_cast<const float4*>(a.xmidF)[fi];
     float4 xs[KCD > 0 ? KCD : 1];
 #pragma unroll
-    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabR + ((int64_t)s * a.rows + b) * 576)[xi];
+    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabF)[(int64_t)s * a.slabF_stride4 + fi];
     const float4 wv = reinterpret_cast<const float4*>(norm_w)[xi];
 #pragma unroll
     for (int s = 0; s < KCD; ++s) v = f4add(v, xs[s]);
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, co
         float4 y;
         y.x = __fmul_rn(wv.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(wv.y, __fmul_rn(v.y, r));
         y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
-        reinterpret_cast<float4*>(a.xnF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = y;
+        reinterpret_cast<float4*>(a.xnF)[fi] = y;
     }
 }
 
@@ -673,7 +678,6 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
         __syncthreads();
         if (tid < 144) {
             const float4 e = reinterpret_cast<const float4*>(embed + (int64_t)tok_s * 576)[tid];
-            reinterpret_cast<float4*>(a.xmidR + (int64_t)b * 576)[tid] = e;
             reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
         }
     }
@@ -686,7 +690,6 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
     const int64_t src = row_ids ? (int64_t)row_ids[b] : (int64_t)b * T_last + (T_last - 1);
     if (tid < 144) {
         const float4 e = reinterpret_cast<const float4*>(in + src * ld)[tid];
-        reinterpret_cast<float4*>(a.xmidR + (int64_t)b * 576)[tid] = e;
         reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
     }
 }
@@ -697,11 +700,10 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
     if (kcd == 0) hipLaunchKernelGGL((dec_qkv_kernel<0>), grid, dim3(256), 0, s, a, Wp, K8p);
     else hipLaunchKernelGGL((dec_qkv_kernel<DEC_KC_DOWN>), grid, dim3(256), 0, s, a, Wp, K8p);
 }
-void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, hipStream_t s) {
-    const dim3 grid(3, a.rows, DEC_TS);
-    if (kcd == 0) hipLaunchKernelGGL((dec_attn_kernel<0>), grid, dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
-    else hipLaunchKernelGGL((dec_attn_kernel<DEC_KC_DOWN>), grid, dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s) {
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(3, a.rows, DEC_TS), dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
 }
+int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
     hipLaunchKernelGGL(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(1024), 0, s, a, Wp16);
 }

@@ -905,6 +905,10 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         e->kv_Tmax = Tmax;
         CHK(ensure(e, e->kcache, kv_layer_floats(e) * e->cfg.num_layers));
         CHK(ensure(e, e->vcache, kv_layer_floats(e) * e->cfg.num_layers));
+        // the decode attention loads whole key groups before it knows the position and masks them afterwards
+        // (weight 0 x value): never-written page slots must hold finite numbers
+        HIPCHK(hipMemsetAsync(e->kcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
+        HIPCHK(hipMemsetAsync(e->vcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
     }
     {
@@ -913,8 +917,8 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         const size_t n_x = (size_t)Bp * 576;
         size_t off = 0;
         auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
-        const size_t o_xmidR = take(n_x), o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x);
-        const size_t o_dslabR = take(DEC_KC_DOWN * n_x), o_dslabF = take(DEC_KC_DOWN * n_x);
+        const size_t o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x);
+        const size_t o_dslabF = take(DEC_KC_DOWN * n_x), o_ssq1 = take((size_t)Bp * DEC_KC_QKV), o_rope = take(64);
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
         const size_t o_att = take((size_t)DEC_TS * n_x), o_am = take((size_t)DEC_TS * 9 * Bp), o_al = take((size_t)DEC_TS * 9 * Bp);
         const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 2 * 256), o_xmidF16 = take(n_x);
@@ -929,10 +933,18 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         }
         float* p = e->dec.p;
         DecArgs& a = e->da;
-        a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0;
+        a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
-        a.xmidR = p + o_xmidR; a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
-        a.dslabR = p + o_dslabR; a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4);
+        a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
+        a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
+        {
+            // key split of the decode attention: balanced at the END of the reserved context, rounded down to whole
+            // passes of a workgroup when that costs at most 4 groups of imbalance
+            const int ng_end = (Tmax - 1 + 3) / 4, chunk = dec_attn_chunk_groups();
+            int gs = (ng_end + DEC_TS - 1) / DEC_TS;
+            if (gs > chunk && gs % chunk <= 4) gs -= gs % chunk;
+            a.gs = gs < 1 ? 1 : gs;
+        }
         a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu; a.xmidF16 = p + o_xmidF16;
         a.logits = e->dlogits.p; a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * (V / 32));
     }
@@ -1032,11 +1044,12 @@ static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int 
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         DecArgs a = e->da;
-        a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // the first kernel of a step advances the position word
+        a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
+        a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 960.0, 576.0 * 960.0 * 4);
           launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
         { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
-          launch_dec_attn(e->da, kc, vc, kcd, s); }
+          launch_dec_attn(e->da, kc, vc, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
           launch_dec_oproj(e->da, w.o16, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);

@@ -72,13 +72,17 @@ struct DecArgs {
     int Tmax = 0;
     float eps = 1e-5f;
     int32_t* d_pos = nullptr;      // device position word: index of the token being processed
-    int inc_pos = 0;               // qkv kernel of layer 0 advances it
+    int first = 0;                 // set on the first qkv launch of a step: stage rope_cur (and, with inc_pos, advance d_pos)
+    int inc_pos = 0;
+    int gs = 1;                    // attention: 4-key groups per key split (fixed per launch; last split takes the rest)
+    float* rope_cur = nullptr;     // [64] cos | sin of the current position
+    float* ssq1 = nullptr;         // [rows][DEC_KC_QKV] per-k-chunk sums of squares of x_new (qkv kernel -> attention)
     const float* rope_cos = nullptr;
     const float* rope_sin = nullptr;
-    // residual stream: "mid" = layer input base (embedding rows / previous layer's x_mid), row-major + F32-layout
-    float* xmidR = nullptr; float* xmidF = nullptr;
-    float* xnewR = nullptr;        // x after the previous down projection, materialised by the attention kernel
-    float* dslabR = nullptr; float* dslabF = nullptr;   // down split-K slabs [DEC_KC_DOWN][rows][576] / F32-layout
+    // residual stream: "mid" = layer input base (embedding rows / previous layer's x_mid), F32-layout
+    float* xmidF = nullptr;
+    float* xnewR = nullptr;        // x after the previous down projection, row-major, materialised by the qkv kernel
+    float* dslabF = nullptr;       // down split-K slabs [DEC_KC_DOWN] x F32-layout
     int64_t slabF_stride4 = 0;     // float4 elements between F-layout slabs
     float* pq = nullptr;           // qkv split-K slabs [DEC_KC_QKV][rows][960]
     float* attF16 = nullptr;       // attention partial outputs [DEC_TS][RB][36][2][64][4] (F16-layout)
@@ -91,7 +95,8 @@ struct DecArgs {
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
 void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s);
-void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, int kcd, hipStream_t s);
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s);
+int dec_attn_chunk_groups();   // 4-key groups one attention workgroup covers per pass
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s);
 void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s);
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s);
