@@ -37,6 +37,9 @@ __device__ __forceinline__ void kstamp(int slot, int idx, bool who) {
 #endif
 void set_kernel_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &p, sizeof(p)); }
 
+// softmax weights: exp(x) = 2^(x*log2 e) on the hardware v_exp_f32 (x <= 0 here; ~1e-6 relative, far inside the fp32
+// summation-order noise of a 64..700-key softmax); exp(-inf) = 0 exactly
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             cm = fmaxf(cm, swz_xor16(cm));
             cm = half_max(cm);
             const float m_new = fmaxf(m_run[hh], cm);       // finite: key 4*g0 of the chunk is valid
-            const float alpha = expf(m_run[hh] - m_new);    // exp(-inf) = 0 on the first chunk
+            const float alpha = fast_exp(m_run[hh] - m_new);    // exp(-inf) = 0 on the first chunk
             m_run[hh] = m_new;
             float lsum = 0.f;
             float4 o = make_float4(acc[hh].x * alpha, acc[hh].y * alpha, acc[hh].z * alpha, acc[hh].w * alpha);
 #pragma unroll
             for (int u = 0; u < DA_G; ++u) {
-                const float p = expf(sc[u][hh] - m_new);    // masked keys: exp(-inf) = 0
+                const float p = fast_exp(sc[u][hh] - m_new);    // masked keys: exp(-inf) = 0
                 lsum += p;
                 o.x += p * v4[u].x; o.y += p * v4[u].y; o.z += p * v4[u].z; o.w += p * v4[u].w;
             }
@@ -297,14 +300,14 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
         float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
         if (M > -INFINITY) {                 // an empty split (short context) publishes m = -inf, l = 0, o = 0
             if (sp == DEC_TS - 1) {
-                const float pn = expf(snew - M);
+                const float pn = fast_exp(snew - M);
                 const float4 vn = *reinterpret_cast<const float4*>(vnew + dq * 4);
                 L = pn;
                 O = make_float4(pn * vn.x, pn * vn.y, pn * vn.z, pn * vn.w);
             }
 #pragma unroll
             for (int w = 0; w < DA_WAVES; ++w) {
-                const float f = expf(mred[w * 3 + hh] - M);     // waves without keys: m = -inf -> factor 0
+                const float f = fast_exp(mred[w * 3 + hh] - M);     // waves without keys: m = -inf -> factor 0
                 const float4 ow = *reinterpret_cast<const float4*>(ored + (w * 3 + hh) * 64 + dq * 4);
                 L += lred[w * 3 + hh] * f;
                 O.x += ow.x * f; O.y += ow.y * f; O.z += ow.z * f; O.w += ow.w * f;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
         float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int s = 0; s < DEC_TS; ++s) {
-            const float f = expf(ms[i][s] - M);
+            const float f = fast_exp(ms[i][s] - M);
             L += ls[i][s] * f;
             O.x += os[i][s].x * f; O.y += os[i][s].y * f; O.z += os[i][s].z * f; O.w += os[i][s].w * f;
         }
