@@ -407,11 +407,10 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K4  full-K projection (gate/up and lm_head).  grid (n-tiles, 1, RB), 4 waves x 18 k-tiles, all 36 loads of a
-//     wave in flight; X in F32-layout.  OUT_GU: writes g/u in the down projection's F32-layout
-//     guF[rb][hidden/8][g|u][lane][4];  OUT_LOGITS: row-major logits + fused arg-max candidates per tile.
+// K4  full-K projection (lm_head).  grid (n-tiles, 1, RB), 4 waves x 18 k-tiles, all 36 loads of a
+//     wave in flight; X in F32-layout.  Writes row-major logits (optional) + fused arg-max candidates per tile.
 // ----------------------------------------------------------------------------------------------------
-enum { OUT_GU = 0, OUT_LOGITS = 1 };
+enum { OUT_LOGITS = 1 };
 template <int OUT>
 __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                         const float* __restrict__ XF, int N) {
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
     const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
     float4 w[KPW], x[KPW];
     const bool dbg = tid == 0 && nt == 0 && rb == 0;
-    const int dslot = OUT == OUT_GU ? 3 : 5;
+    const int dslot = 5;
     kstamp(dslot, 0, dbg);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) { w[i] = wp[i * 64]; x[i] = xp[i * 64]; }
@@ -448,14 +447,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
         v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) +
                (red[(2 * 16 + r) * 64 + mm + 32 * hh] + red[(3 * 16 + r) * 64 + mm + 32 * hh]);
     }
-    if (OUT == OUT_GU) {
-        // n-tile nt = 2*jj + is_up (pair-interleaved gate/up packing); hidden unit = 32*jj + 8*gq + 4*hh + (0..3)
-        const int jj = nt >> 1, is_up = nt & 1;
-        const int kd = 4 * jj + gq;                                   // k-tile of the down projection
-        reinterpret_cast<float4*>(a.guF)[((((int64_t)rb * 192 + kd) * 2 + is_up) * 64) + mm + 32 * hh] =
-            make_float4(v[0], v[1], v[2], v[3]);
-        kstamp(dslot, 4, dbg);
-    } else {
+    {
         const int n = nt * 32 + 8 * gq + 4 * hh;
         const int64_t row = (int64_t)rb * 32 + mm;
         if (a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -486,11 +478,11 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K4b gate/up projection on 16-row weight tiles.  grid (192 n16-tiles, RB), 4 waves x 9 k16-tiles,
-//     v_mfma_f32_16x16x4_f32; W = folded gate/up in P16-layout with (gate, up) interleaved at 16 rows:
-//     tile 2j = gate[16j..16j+15], tile 2j+1 = up[16j..16j+15].  X = x_mid in F16-layout.
-//     192 workgroups x (36 KB of W + 72 KB of X); the dependent MFMA chain per wave is 72 x 32 cycles.
-//     writes g/u in the down projection's F32-layout guF[rb][hidden/8][g|u][lane][4].
+// K4b gate/up projection + SwiGLU on 16-row weight tiles.  grid (192 n16-tiles, RB), 4 waves x 9 k16-tiles,
+//     v_mfma_f32_16x16x4_f32; W = folded gate/up in P16-layout, tile t = gate[8t..8t+7] | up[8t..8t+7];
+//     X = x_mid in F16-layout.  192 workgroups x (36 KB of W + 72 KB of X).
+//     epilogue: r2[m] = rsqrt(mean(x_mid[m]^2) + eps) from the o_proj's per-tile sums;
+//     h = silu(r2 g) * (r2 u)  ->  hF[rb][hidden/8][lane][4]  (F32-layout B operand of the down projection)
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
     __shared__ __attribute__((aligned(16))) float red[4 * 8 * 64];   // 8 KiB
@@ -500,12 +492,18 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
     const int t0 = wave * TPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * K16 + t0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
-    float4 w[TPW], x0[TPW], x1[TPW];
+    // epilogue thread (m = tid>>1, q = tid&1), tid < 64: its row's 36 sum-of-squares partials, issued up front
+    const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + ((tid >> 1) & 31)) * 40);
+    float4 w[TPW], x0[TPW], x1[TPW], s4[9];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         w[i] = wp[i * 64];
         x0[i] = xp[(i * 2) * 64];
         x1[i] = xp[(i * 2 + 1) * 64];
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) s4[j] = sq[j];
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -526,64 +524,57 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
         red[(wave * 8 + 4 + r) * 64 + lane] = acc1[r];
     }
     __syncthreads();
-    if (tid < 128) {
-        // thread (m = 0..31, nq = 0..3): columns 4*nq + r are registers r of lane (m&15) + 16*nq, accumulator m>>4
-        const int m = tid >> 2, nq = tid & 3;
-        const int src_lane = (m & 15) + 16 * nq, rbase = (m >> 4) * 4;
-        float v[4];
+    if (tid < 64) {
+        // D[i = tile row 4*(lane>>4) + r][j = batch row lane&15], accumulator (m>>4).  Tile rows 0..7 = gate of hidden
+        // units 8nt..8nt+7, rows 8..15 = up of the same units: thread (m, q) combines gate rows 4q..4q+3 (lane group q)
+        // with up rows 8+4q.. (lane group q+2).
+        const int m = tid >> 1, q = tid & 1;
+        const int gl = (m & 15) + 16 * q, ul = gl + 32, rbase = (m >> 4) * 4;
+        float ss = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            v[r] = (red[(0 * 8 + rbase + r) * 64 + src_lane] + red[(1 * 8 + rbase + r) * 64 + src_lane]) +
-                   (red[(2 * 8 + rbase + r) * 64 + src_lane] + red[(3 * 8 + rbase + r) * 64 + src_lane]);
-        // hidden unit = 16*(nt>>1) + 4*nq + r  ->  down k-tile kd = 2*(nt>>1) + (nq>>1), lane' = m + 32*(nq&1)
-        const int is_up = nt & 1, kd = 2 * (nt >> 1) + (nq >> 1);
-        reinterpret_cast<float4*>(a.guF)[(((int64_t)rb * 192 + kd) * 2 + is_up) * 64 + m + 32 * (nq & 1)] =
-            make_float4(v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < 9; ++j) ss += (s4[j].x + s4[j].y) + (s4[j].z + s4[j].w);
+        const float r2 = 1.0f / sqrtf(ss / 576.0f + a.eps);
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gv = (red[(0 * 8 + rbase + r) * 64 + gl] + red[(1 * 8 + rbase + r) * 64 + gl]) +
+                             (red[(2 * 8 + rbase + r) * 64 + gl] + red[(3 * 8 + rbase + r) * 64 + gl]);
+            const float uv = (red[(0 * 8 + rbase + r) * 64 + ul] + red[(1 * 8 + rbase + r) * 64 + ul]) +
+                             (red[(2 * 8 + rbase + r) * 64 + ul] + red[(3 * 8 + rbase + r) * 64 + ul]);
+            h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
+        }
+        // hidden unit k = 8*nt + 4*q + r: down k-tile nt, F32-layout lane' = m + 32*q
+        reinterpret_cast<float4*>(a.guF)[((int64_t)rb * 192 + nt) * 64 + m + 32 * q] = make_float4(h[0], h[1], h[2], h[3]);
     }
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K5  down projection, split-K.  grid (18 n-tiles, DEC_KC_DOWN, RB), 6 waves x 8 k-tiles.
-//     r2[m] = rsqrt(mean(x_mid[m]^2) + eps) from the o_proj's per-tile sums;  X = silu(r2 g) * (r2 u)
-//     out: down slabs row-major (attention / final norm) + F32-layout (next layer's qkv)
+// K5  down projection, split-K.  grid (18 n-tiles, DEC_KC_DOWN, RB), 6 waves x 4 k-tiles.
+//     X = h (SwiGLU output of K4b, F32-layout);  out: down slabs in F32-layout (next layer's qkv / final norm)
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
     __shared__ __attribute__((aligned(16))) float red[6 * 16 * 64];   // 24 KiB
-    constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 8
+    constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
-    const int m = lane & 31;
     const int k8_0 = (kc * 6 + wave) * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
-    const float4* gp = reinterpret_cast<const float4*>(a.guF) + (((int64_t)rb * 192 + k8_0) * 2) * 64 + lane;
-    const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + m) * 40);
+    const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
     const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
     kstamp(4, 0, dbg);
-    float4 s4[9], w[KPW], g4[KPW], u4[KPW];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s4[j] = sq[j];
+    float4 w[KPW], h4[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         w[i] = wp[i * 64];
-        g4[i] = gp[(i * 2) * 64];
-        u4[i] = gp[(i * 2 + 1) * 64];
+        h4[i] = hp[i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(4, 1, dbg);
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) ss += (s4[j].x + s4[j].y) + (s4[j].z + s4[j].w);
-    const float r = 1.0f / sqrtf(ss / 576.0f + a.eps);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        float4 xv;
-        xv.x = __fmul_rn(siluf_(g4[i].x * r), u4[i].x * r); xv.y = __fmul_rn(siluf_(g4[i].y * r), u4[i].y * r);
-        xv.z = __fmul_rn(siluf_(g4[i].z * r), u4[i].z * r); xv.w = __fmul_rn(siluf_(g4[i].w * r), u4[i].w * r);
-        acc = mfma4(acc, w[i], xv);
-    }
+    for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], h4[i]);
     kstamp(4, 2, dbg && acc[0] == acc[0]);
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[q];
@@ -601,8 +592,7 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
             v[j] = sacc;
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
-        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
+        reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = make_float4(v[0], v[1], v[2], v[3]);
     }
     kstamp(4, 4, dbg);
 }

@@ -96,7 +96,7 @@ struct LMLayerW {
     Packed qkv, o, gateup, down;       // prefill (plain weights, P-layout); `down` is also the decode operand
     Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
     float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
-    float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, (gate, up) interleaved at 16 rows
+    float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, tile = 8 gate rows + the 8 matching up rows
     float *in_ln, *post_ln;
 };
 
@@ -679,10 +679,12 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                     uf[(size_t)n * H + kk] = u->f()[(size_t)n * H + kk] * l2->f()[kk];
                 }
             {
-                std::vector<float> il((size_t)2 * I * H);     // rows: gate[16j..16j+15], up[16j..16j+15], j = 0..95
-                for (int j = 0; j < I / 16; ++j) {
-                    memcpy(il.data() + (size_t)(2 * j) * 16 * H, gf.data() + (size_t)j * 16 * H, (size_t)16 * H * 4);
-                    memcpy(il.data() + (size_t)(2 * j + 1) * 16 * H, uf.data() + (size_t)j * 16 * H, (size_t)16 * H * 4);
+                // 16-row tile t = gate[8t..8t+7] then up[8t..8t+7]: one workgroup of the decode gate/up kernel owns both
+                // halves of 8 hidden units and applies the SwiGLU in its epilogue
+                std::vector<float> il((size_t)2 * I * H);
+                for (int t = 0; t < I / 8; ++t) {
+                    memcpy(il.data() + (size_t)(2 * t) * 8 * H, gf.data() + (size_t)t * 8 * H, (size_t)8 * H * 4);
+                    memcpy(il.data() + (size_t)(2 * t + 1) * 8 * H, uf.data() + (size_t)t * 8 * H, (size_t)8 * H * 4);
                 }
                 CHK(make_packed16(e, il.data(), 2 * I, H, &w.gu16));
             }
@@ -921,7 +923,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         const size_t o_dslabF = take(DEC_KC_DOWN * n_x), o_ssq1 = take((size_t)Bp * DEC_KC_QKV), o_rope = take(64);
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
         const size_t o_att = take((size_t)DEC_TS * n_x), o_am = take((size_t)DEC_TS * 9 * Bp), o_al = take((size_t)DEC_TS * 9 * Bp);
-        const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 2 * 256), o_xmidF16 = take(n_x);
+        const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 256), o_xmidF16 = take(n_x);
         const bool fresh = e->dec.cap < off;
         CHK(ensure(e, e->dec, off));
         CHK(ensure(e, e->dlogits, (size_t)Bp * V));

@@ -89,7 +89,7 @@ struct DecArgs {
     float* att_m = nullptr; float* att_l = nullptr;     // [DEC_TS][9][rows]
     float* ssq = nullptr;          // [rows][40] per-o_proj-tile sums of squares of x_mid
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
-    float* guF = nullptr;          // gate/up [RB][192][2][64][4] (F32-layout of the down projection)
+    float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)
     float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
