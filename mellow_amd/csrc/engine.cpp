@@ -104,6 +104,7 @@ struct ProfRec {
     int fam;
     hipEvent_t a, b;
     double flops, bytes;
+    int M = 0, N = 0, K = 0, epi = 0;     // GEMM launches only (developer shape report)
 };
 
 struct mellow_engine {
@@ -729,6 +730,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
 // ---- GEMM wrappers -------------------------------------------------------------------------------------------------------
 static int run_gemm(mellow_engine* e, const GemmArgs& a) {
     ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+    ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi;
     launch_gemm(a, e->stream);
     return 0;
 }
@@ -1297,6 +1299,51 @@ int mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms
     if (decode_ms) *decode_ms = e->phase_ms[2];
     return 0;
 }
+// developer instrumentation (not part of the public header): time `iters` launches of one plain GEMM shape on
+// synthetic device buffers (garbage-in; EPI_LINEAR, no bias) -> average milliseconds per launch
+int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, float* ms_out) {
+    if (!e || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || iters <= 0 || !ms_out) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    float *A = nullptr, *W = nullptr, *Cc = nullptr;
+    const size_t NP = (size_t)rup(N, 128);
+    HIPCHK(hipMalloc(&A, (size_t)M * K * 4));
+    HIPCHK(hipMalloc(&W, NP * K * 4));
+    HIPCHK(hipMalloc(&Cc, (size_t)M * N * 4));
+    HIPCHK(hipMemsetAsync(A, 0x3c, (size_t)M * K * 4, e->stream));      // 0x3c3c3c3c = 0.0115 (finite, non-zero)
+    HIPCHK(hipMemsetAsync(W, 0x3c, NP * K * 4, e->stream));
+    GemmArgs g;
+    g.A = A; g.lda = K; g.M = M; g.K = K; g.Wp = W; g.Nw = N; g.N = N; g.C = Cc; g.ldc = N;
+    launch_gemm(g, e->stream);
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, e->stream));
+    for (int i = 0; i < iters; ++i) launch_gemm(g, e->stream);
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / iters;
+    hipEventDestroy(a); hipEventDestroy(b);
+    hipFree(A); hipFree(W); hipFree(Cc);
+    return 0;
+}
+// developer instrumentation (not part of the public header): one CSV line per profiled launch
+int mellow_dev_prof_dump(mellow_engine_t* e, const char* path) {
+    if (!e || !path) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    FILE* f = fopen(path, "w");
+    if (!f) return fail("cannot open %s", path);
+    fprintf(f, "fam,M,N,K,epi,ms,flops\n");
+    for (const auto& r : e->prof) {
+        float m = 0.f;
+        hipEventElapsedTime(&m, r.a, r.b);
+        fprintf(f, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.fam, r.M, r.N, r.K, r.epi, m, r.flops);
+    }
+    fclose(f);
+    return 0;
+}
 // developer instrumentation (not part of the public header): s_memtime stamps of workgroup 0 of the decode kernels
 int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
     if (!e) return fail("null engine");
@@ -1306,10 +1353,12 @@ int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
         if (!buf) HIPCHK(hipMalloc(&buf, 64 * sizeof(uint64_t)));
         HIPCHK(hipMemset(buf, 0, 64 * sizeof(uint64_t)));
         set_kernel_debug_buffer(buf);
+        set_gemm_debug_buffer(buf);
     } else {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (buf && host_out64) HIPCHK(hipMemcpy(host_out64, buf, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         set_kernel_debug_buffer(nullptr);
+        set_gemm_debug_buffer(nullptr);
     }
     return 0;
 }

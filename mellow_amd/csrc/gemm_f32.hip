@@ -16,7 +16,8 @@
 //    output ROW and four consecutive columns per accumulator quad -> float4 epilogue stores, and the
 //    two halves of a (re,im) / (gate,up) / RoPE pair sit in the same lane.
 //  * 4 waves per workgroup, 64x64 per wave (4 accumulators), block 128x128 or 256x64, BK = 32,
-//    double-buffered LDS with register prefetch (one barrier per k-tile).
+//    double-buffered LDS fed by a two-tile-deep register prefetch (one barrier per k-tile),
+//    MFMA fragments double-buffered in registers.
 //  * XCD-aware block order: all n-blocks of an m-panel run on one XCD (A panel read once per L2).
 #include <cstdlib>
 
@@ -29,6 +30,10 @@ struct GemmDev {
     GemmArgs a;
     int gm, gn;
 };
+// developer instrumentation (-DMELLOW_KDEBUG): slot 7 of the debug buffer = main-loop {shader clocks, 100 MHz ticks,
+// k-tiles, grid} of a mid-grid workgroup of the last GEMM launch
+__device__ uint64_t* g_kdbg = nullptr;
+void set_gemm_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &p, sizeof(p)); }
 
 template <int WM, int WN, int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
@@ -46,6 +51,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
 
     const GemmArgs& g = p.a;
     const int tid = threadIdx.x;
+#ifdef MELLOW_KDEBUG
+    const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = wall_clock64();
+#endif
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -96,64 +104,118 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_F4], rw[W_F4];
-#pragma unroll
-    for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q]);
-#pragma unroll
-    for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][0];
-#pragma unroll
-    for (int q = 0; q < A_F4; ++q) As[a_lds[q]] = ra[q];
-#pragma unroll
-    for (int q = 0; q < W_F4; ++q) Ws[w_lds[q]] = rw[q];
-    __syncthreads();
+    // ---- main loop: 3-deep software pipeline -------------------------------------------------------------------
+    //   G(t): global -> registers,  S(t): registers -> LDS[t & 1],  C(t): MFMAs from LDS[t & 1]
+    //   iteration t:  G(t+2) ; C(t) ; S(t+1) ; barrier
+    // A tile's global loads are issued two compute phases before they are needed: with one workgroup per CU (small
+    // grids: encoder stage 3, tscam) nothing else hides the L2/HBM latency, +20..30 % there; neutral on the large LM
+    // shapes, where the second workgroup of the CU already covered it.  Two register sets, k-loop unrolled by two so
+    // that every array index is static.  Tile indices are clamped (the tail harmlessly re-reads the last tile).
+    // native vector type, not HIP's float4 struct: struct copies become llvm.memcpy through a private alloca that the
+    // compiler did not promote for this loop shape (every prefetch went through scratch memory)
+    f32x4 ra0[A_F4], rw0[W_F4], ra1[A_F4], rw1[W_F4];
+#define MELLOW_GLOAD(RA, RW, T)                                                                      \
+    {                                                                                                \
+        const int t_ = (T) < KT ? (T) : KT - 1;                                                      \
+        _Pragma("unroll") for (int q = 0; q < A_F4; ++q)                                             \
+            RA[q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + t_ * BK);                              \
+        _Pragma("unroll") for (int q = 0; q < W_F4; ++q) RW[q] = reinterpret_cast<const f32x4*>(w_ptr[q])[(int64_t)t_ * KS * 64]; \
+    }
+#define MELLOW_LSTORE(RA, RW, STAGE)                                                                 \
+    {                                                                                                \
+        f32x4* An = reinterpret_cast<f32x4*>(As + (STAGE) * A_STAGE);                                \
+        f32x4* Wn = reinterpret_cast<f32x4*>(Ws + (STAGE) * W_STAGE);                                \
+        _Pragma("unroll") for (int q = 0; q < A_F4; ++q) An[a_lds[q]] = RA[q];                       \
+        _Pragma("unroll") for (int q = 0; q < W_F4; ++q) Wn[w_lds[q]] = RW[q];                       \
+    }
+#define MELLOW_MFMA16(w0, w1, a0, a1)                                                                \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a0.x, acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a1.x, acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a0.x, acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a1.x, acc[1][1], 0, 0, 0);                \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a0.y, acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a1.y, acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a0.y, acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a1.y, acc[1][1], 0, 0, 0);                \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a0.z, acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a1.z, acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a0.z, acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a1.z, acc[1][1], 0, 0, 0);                \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a0.w, acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a1.w, acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a0.w, acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a1.w, acc[1][1], 0, 0, 0);
+    // fragments double-buffered in registers: the LDS reads of sub-step k8+1 are issued before the 16 MFMAs of k8.
+    // STORE (the LDS refill of the other stage, or nothing) is placed between the two MFMA groups of the LAST sub-step
+    // pair: its ds_writes drain while the matrix pipe works, so the exposed part of the refill is the barrier and the
+    // first fragment reads.  Where the remaining ~20 % of the loop goes was measured with tools/microbench/gemm_ablate.hip
+    // (same loop, switchable parts): MFMA + LDS reads + barrier alone sustain 148-151 TFLOP/s; adding the
+    // LDS refill or the global prefetch costs ~5 % EACH even when a different, idle wave issues them (8-wave ping-pong
+    // variant), i.e. it is contention inside the CU, not exposed latency, and no instruction order removes it.
+#define MELLOW_COMPUTE(STAGE, STORE)                                                                 \
+    if (wave_active) {                                                                               \
+        const f32x4* Ac = reinterpret_cast<const f32x4*>(As + (STAGE) * A_STAGE + (2 * wm) * 64 + lane); \
+        const f32x4* Wc = reinterpret_cast<const f32x4*>(Ws + (STAGE) * W_STAGE + (2 * wn) * 64 + lane); \
+        f32x4 xa0 = Ac[0], xa1 = Ac[64], xw0 = Wc[0], xw1 = Wc[64];                                  \
+        _Pragma("unroll") for (int k8 = 0; k8 < KS; k8 += 2) {                                       \
+            const f32x4 ya0 = Ac[((k8 + 1) * MT) * 64], ya1 = Ac[((k8 + 1) * MT + 1) * 64];          \
+            const f32x4 yw0 = Wc[((k8 + 1) * NTB) * 64], yw1 = Wc[((k8 + 1) * NTB + 1) * 64];        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+            MELLOW_MFMA16(xw0, xw1, xa0, xa1)                                                        \
+            if (k8 + 2 < KS) {                                                                       \
+                xa0 = Ac[((k8 + 2) * MT) * 64]; xa1 = Ac[((k8 + 2) * MT + 1) * 64];                  \
+                xw0 = Wc[((k8 + 2) * NTB) * 64]; xw1 = Wc[((k8 + 2) * NTB + 1) * 64];                \
+            } else {                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                   \
+                STORE                                                                                \
+            }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+            MELLOW_MFMA16(yw0, yw1, ya0, ya1)                                                        \
+        }                                                                                            \
+    } else {                                                                                         \
+        STORE                                                                                        \
+    }
+    static_assert(KS % 2 == 0, "k sub-steps are processed in pairs");
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        // prefetch the next k-tile into registers (the last iteration harmlessly re-reads its own tile so the
-        // register arrays stay unconditional and are never demoted to scratch)
-        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
-#pragma unroll
-        for (int q = 0; q < A_F4; ++q) ra[q] = *reinterpret_cast<const float4*>(a_ptr[q] + ktn * BK);
-#pragma unroll
-        for (int q = 0; q < W_F4; ++q) rw[q] = w_ptr[q][(int64_t)ktn * KS * 64];
-        const float4* Ac = As + cur * A_STAGE;
-        const float4* Wc = Ws + cur * W_STAGE;
-        if (wave_active) {
-#pragma unroll
-        for (int k8 = 0; k8 < KS; ++k8) {
-            const float4 a0 = Ac[(k8 * MT + 2 * wm) * 64 + lane];
-            const float4 a1 = Ac[(k8 * MT + 2 * wm + 1) * 64 + lane];
-            const float4 w0 = Wc[(k8 * NTB + 2 * wn) * 64 + lane];
-            const float4 w1 = Wc[(k8 * NTB + 2 * wn + 1) * 64 + lane];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a0.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a1.x, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a0.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a1.x, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a0.y, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a1.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a0.y, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a1.y, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a0.z, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a1.z, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a0.z, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a1.z, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a0.w, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a1.w, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a0.w, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a1.w, acc[1][1], 0, 0, 0);
-        }
-        }
-        {
-            float4* An = As + (cur ^ 1) * A_STAGE;
-            float4* Wn = Ws + (cur ^ 1) * W_STAGE;
-#pragma unroll
-            for (int q = 0; q < A_F4; ++q) An[a_lds[q]] = ra[q];
-#pragma unroll
-            for (int q = 0; q < W_F4; ++q) Wn[w_lds[q]] = rw[q];
-        }
+    MELLOW_GLOAD(ra0, rw0, 0)
+    MELLOW_GLOAD(ra1, rw1, 1)
+    MELLOW_LSTORE(ra0, rw0, 0)
+    __syncthreads();
+#ifdef MELLOW_KDEBUG
+    uint64_t dbg_tc = 0, dbg_ts = 0, dbg_t = __builtin_readcyclecounter();
+#define MELLOW_DBG_MARK(ACC) { const uint64_t n_ = __builtin_readcyclecounter(); ACC += n_ - dbg_t; dbg_t = n_; }
+#else
+#define MELLOW_DBG_MARK(ACC)
+#endif
+    for (int kt = 0; kt + 1 < KT; kt += 2) {       // no conditional inside: the register arrays must stay unconditional
+        MELLOW_GLOAD(ra0, rw0, kt + 2)
+        MELLOW_DBG_MARK(dbg_ts)
+        MELLOW_COMPUTE(0, MELLOW_LSTORE(ra1, rw1, 1))
+        MELLOW_DBG_MARK(dbg_tc)
+        __syncthreads();
+        MELLOW_GLOAD(ra1, rw1, kt + 3)
+        MELLOW_DBG_MARK(dbg_ts)
+        MELLOW_COMPUTE(1, MELLOW_LSTORE(ra0, rw0, 0))
+        MELLOW_DBG_MARK(dbg_tc)
         __syncthreads();
     }
+    if (KT & 1) { MELLOW_COMPUTE(0, ) }             // odd tile count: the last tile sits in stage 0
+#undef MELLOW_GLOAD
+#undef MELLOW_LSTORE
+#undef MELLOW_MFMA16
+#undef MELLOW_COMPUTE
 
+#ifdef MELLOW_KDEBUG
+    if (g_kdbg && tid == 0 && blockIdx.x == gridDim.x / 2 && acc[0][0][0] == acc[0][0][0]) {
+        g_kdbg[56] = __builtin_readcyclecounter() - dbg_c0;
+        g_kdbg[57] = wall_clock64() - dbg_r0;
+        g_kdbg[58] = (uint64_t)KT;
+        g_kdbg[59] = (uint64_t)gridDim.x;
+        g_kdbg[60] = dbg_tc;
+        g_kdbg[61] = dbg_ts;
+        g_kdbg[62] = __builtin_amdgcn_s_getreg(0xf804);    // HW_REG_HW_ID bits 15:0
+    }
+#endif
     // ---- epilogue: lane owns row m_local = lane&31 of each m-tile, columns 8g + 4h + (0..3) ----------
     const int h = lane >> 5;
 #pragma unroll

@@ -113,6 +113,7 @@ void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, 
 void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s);
 // developer instrumentation: device buffer of 64 uint64 slots stamped by workgroup 0 of the decode kernels (null = off)
 void set_kernel_debug_buffer(uint64_t* p);
+void set_gemm_debug_buffer(uint64_t* p);
 
 // ---- front-end ---------------------------------------------------------------------------------------
 void launch_reflect_pad(const float* wav, int n_clips, int64_t n_samples, float* out, int64_t padded_len, int pad,
