@@ -17,6 +17,8 @@
 namespace mellow {
 
 constexpr int PA_KT_STRIDE = 33;   // transposed K tile row stride (floats): conflict-free b32 reads/writes
+// softmax weights on the hardware exp2 (x <= 0; ~1e-6 relative, inside fp32 summation-order noise); exp(-inf) = 0
+__device__ __forceinline__ float pa_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __restrict__ q,
                                                                 const float* __restrict__ k_cache,
@@ -24,7 +26,8 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
                                                                 float* __restrict__ o, int T, int Tmax) {
     __shared__ __attribute__((aligned(16))) float Kt[64 * PA_KT_STRIDE];   // [d][key]
     __shared__ __attribute__((aligned(16))) float Vs[32 * 64];             // [key][d]
-    const int qt = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    // heavy tiles first: a query tile qt walks qt+1 key tiles (causal), so the long workgroups must not start last
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hq = 3 * g + wave;
     const int h = lane >> 5, ql = lane & 31;
@@ -33,6 +36,30 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
     const int qc = qi < T ? qi : T - 1;
     const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
     const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+
+    // staging roles: 512 float4 per operand tile over 192 threads = 3 slots per thread (the last one partly idle;
+    // idle slots re-read float4 0 and skip the LDS store)
+    int st_key[3], st_quad[3];
+    bool st_on[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = tid + 192 * j;
+        st_on[j] = i < 512;
+        const int ic = st_on[j] ? i : 0;
+        st_key[j] = ic >> 4;
+        st_quad[j] = ic & 15;
+    }
+    f32x4 pk[3], pv[3];                                  // next tile, in flight while the current one is computed
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int t = kt * 32 + st_key[j];
+            t = t < T ? t : T - 1;
+            pk[j] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + st_quad[j] * 4);
+            pv[j] = *reinterpret_cast<const f32x4*>(vpage + (int64_t)t * 64 + st_quad[j] * 4);
+        }
+    };
+    fetch(0);
 
     // Q as MFMA B operand: step s holds Q[query][2s + h], pre-scaled by 1/8 (exact)
     float qreg[32];
@@ -49,20 +76,20 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
     for (int kt = 0; kt <= qt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        // stage K (transposed) and V (row-major): 512 float4 each, 192 threads
-        for (int i = tid; i < 512; i += 192) {
-            const int key = i >> 4, quad = i & 15;
-            int t = k0 + key;
-            t = t < T ? t : T - 1;
-            const float4 kv = *reinterpret_cast<const float4*>(kpage + (int64_t)t * 64 + quad * 4);
-            Kt[(quad * 4 + 0) * PA_KT_STRIDE + key] = kv.x;
-            Kt[(quad * 4 + 1) * PA_KT_STRIDE + key] = kv.y;
-            Kt[(quad * 4 + 2) * PA_KT_STRIDE + key] = kv.z;
-            Kt[(quad * 4 + 3) * PA_KT_STRIDE + key] = kv.w;
-            const float4 vv = *reinterpret_cast<const float4*>(vpage + (int64_t)t * 64 + quad * 4);
-            *reinterpret_cast<float4*>(Vs + key * 64 + quad * 4) = vv;
+        // stage K (transposed) and V (row-major) from the prefetch registers
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (st_on[j]) {
+                const int key = st_key[j], quad = st_quad[j];
+                Kt[(quad * 4 + 0) * PA_KT_STRIDE + key] = pk[j].x;
+                Kt[(quad * 4 + 1) * PA_KT_STRIDE + key] = pk[j].y;
+                Kt[(quad * 4 + 2) * PA_KT_STRIDE + key] = pk[j].z;
+                Kt[(quad * 4 + 3) * PA_KT_STRIDE + key] = pk[j].w;
+                *reinterpret_cast<f32x4*>(Vs + key * 64 + quad * 4) = pv[j];
+            }
         }
         __syncthreads();
+        fetch(kt < qt ? kt + 1 : kt);                    // unconditional (the last iteration re-reads its own tile)
 
         // S^T[key][query] = sum_d K[key][d] Q[query][d]
         f32x16 S;
@@ -81,17 +108,17 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
             if (key > qi) S[r] = -INFINITY;          // causal mask (only bites on the diagonal tile)
             tmax = fmaxf(tmax, S[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = half_max(tmax);                       // the other 16 keys of this query live in lane ^ 32
         const float m_new = fmaxf(m_run, tmax);      // finite: key k0 <= q0 <= qi is never masked
-        const float alpha = expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+        const float alpha = pa_exp(m_run - m_new);   // exp(-inf) = 0 on the first tile
         float rsum = 0.f;
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p[r] = expf(S[r] - m_new);
+            p[r] = pa_exp(S[r] - m_new);
             rsum += p[r];
         }
-        rsum += __shfl_xor(rsum, 32, 64);
+        rsum = half_sum(rsum);
         l_run = l_run * alpha + rsum;
         m_run = m_new;
 #pragma unroll
