@@ -9,7 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-enum { F_GLOAD = 1, F_STORE = 2, F_BARRIER = 4, F_LDSREAD = 8, F_STORE_LATE = 16, F_L2HOT = 32, F_DEEP = 64, F_STAMP = 128 };
+enum { F_GLOAD = 1, F_STORE = 2, F_BARRIER = 4, F_LDSREAD = 8, F_STORE_LATE = 16, F_L2HOT = 32, F_DEEP = 64, F_STAMP = 128, F_DIRECT = 256 };
 __device__ unsigned long long g_stamp[8];
 
 #define MFMA16(w0, w1, a0, a1)                                                                        \
@@ -55,7 +55,15 @@ __global__ __launch_bounds__(256) void loop_kernel(const f32x4* __restrict__ A, 
     const unsigned long long t_begin = __builtin_readcyclecounter();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (FL & F_GLOAD) {
+        if (FL & F_DIRECT) {
+            // global -> LDS without a VGPR round trip: lane i of the wave lands at base + 16 i
+            f32x4* dst = smem + (cur ^ 1) * 2048 + wave * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_global_load_lds(ap + (kt & 63) * 1024 + q * 256, dst + q * 256, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(wp + (kt & 63) * 1024 + q * 256, dst + 1024 + q * 256, 16, 0, 0);
+            }
+        } else if (FL & F_GLOAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { ra[q] = ap[(kt & 63) * 1024 + q * 256]; rw[q] = wp[(kt & 63) * 1024 + q * 256]; }
         }
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(256) void loop_kernel(const f32x4* __restrict__ A, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) { An[q * 256 + tid] = ra[q]; An[1024 + q * 256 + tid] = rw[q]; }
         }
+        if (FL & F_DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FL & F_BARRIER) __syncthreads();
         if (FL & F_STAMP) w_bar += __builtin_readcyclecounter() - t0;
     }
@@ -234,6 +243,8 @@ int main() {
         run<F_L2HOT | F_GLOAD | F_LDSREAD | F_STORE | F_STORE_LATE | F_BARRIER>("full loop, L2-hot operands (writes end)", A, W, out, blocks, KT);
         run<F_STAMP | F_L2HOT | F_GLOAD | F_LDSREAD | F_STORE | F_STORE_LATE | F_BARRIER>("full loop, L2-hot (writes end), stamped", A, W, out, blocks, KT);
         run<F_STAMP | F_LDSREAD | F_STORE | F_STORE_LATE | F_BARRIER>("no global loads (writes end), stamped", A, W, out, blocks, KT);
+        run<F_L2HOT | F_DIRECT | F_LDSREAD | F_BARRIER>("full loop, L2-hot, direct-to-LDS loads", A, W, out, blocks, KT);
+        run<F_DIRECT | F_LDSREAD | F_BARRIER>("full loop, private streams, direct-to-LDS loads", A, W, out, blocks, KT);
         run_pp<F_STORE | F_GLOAD>("8-wave ping-pong 256x128, full loop, L2-hot", A, W, out, blocks / 2, KT);
         run_pp<0>("8-wave ping-pong 256x128, mfma + lds reads + barriers", A, W, out, blocks / 2, KT);
         run_pp<F_STORE>("8-wave ping-pong 256x128, + lds writes only", A, W, out, blocks / 2, KT);
