@@ -69,6 +69,28 @@ def cpu_baseline(max_len: int, threads: int):
     }
 
 
+def pipelined(n_ctx: int, B: int, L: int, n_batches: int):
+    """Supplementary: n_ctx engine contexts on one GPU, n_batches batches of B dealt round-robin (mellow_amd/serve.py)."""
+    from mellow_amd import synth
+    from mellow_amd.serve import EnginePool
+    pool = EnginePool(synth.make_state_dict(0), n_contexts=n_ctx, device=0)
+    batches = []
+    for i in range(n_batches):
+        a1, a2, ids = synth.make_batch(B, first=i * B)
+        e = pool.engines[i % n_ctx]
+        batches.append((e._f32(a1), e._f32(a2), e._i32(ids)))
+    kw = dict(max_len=L, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
+    pool.generate_many(batches[: n_ctx], **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pool.generate_many(batches, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pool.close()
+    return {"contexts": n_ctx, "batches": n_batches, "value": round(n_batches * B / dt, 2), "unit": "responses/s",
+            "note": "throughput mode for a serving front-end: independent batches overlap on one GPU; per-batch latency is worse"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +99,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="examples per GPU")
     ap.add_argument("--max-len", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="also measure N engine contexts pipelining the same batches on this GPU (supplementary "
+                         "'pipelined' object; never the headline value)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +193,8 @@ def main():
                               "definition": "F_dense/157.3TF + Bytes_decode/8TB/s per response x batch (SURVEY 8d)"},
             "kernel_families_ms": {k: round(v["ms"], 3) for k, v in rep.items()},
         }
+        if n_gpus == 1 and args.inflight > 1:
+            out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, threads=min(32, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)

@@ -351,3 +351,15 @@ def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
         want = O.generate_batch(synth_sd, O.LMParams(), prefix, 4, 0.8, 1.0, -1)
     _close(engine.prefix(a1[:1], a2[:1], ids[:1]), prefix, name="30 s prefix")
     assert np.array_equal(t[0, :4], np.asarray(want)[0])
+
+
+def test_pipelined_contexts_give_identical_tokens(engine, synth_sd):
+    """mellow_amd.serve.EnginePool: two contexts on one GPU, batches in flight concurrently == one engine, batch by batch."""
+    from mellow_amd.serve import EnginePool
+    pool = EnginePool(synth_sd, n_contexts=2, device=0)
+    batches = [synth.make_batch(3, first=3 * i) for i in range(4)]
+    got = pool.generate_many(batches, max_len=6, stop_id=0, ignore_stop=True)
+    pool.close()
+    for (a1, a2, ids), res in zip(batches, got):
+        want, *_ = engine.generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
+        assert np.array_equal(res[0], want)
