@@ -110,13 +110,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     // A tile's global loads are issued two compute phases before they are needed: with one workgroup per CU (small
     // grids: encoder stage 3, tscam) nothing else hides the L2/HBM latency, +20..30 % there; neutral on the large LM
     // shapes, where the second workgroup of the CU already covered it.  Two register sets, k-loop unrolled by two so
-    // that every array index is static.  Tile indices are clamped (the tail harmlessly re-reads the last tile).
+    // that every array index is static.  Prefetches past the last k-tile are skipped (uniform branch).
     // native vector type, not HIP's float4 struct: struct copies become llvm.memcpy through a private alloca that the
     // compiler did not promote for this loop shape (every prefetch went through scratch memory)
     f32x4 ra0[A_F4], rw0[W_F4], ra1[A_F4], rw1[W_F4];
 #define MELLOW_GLOAD(RA, RW, T)                                                                      \
-    {                                                                                                \
-        const int t_ = (T) < KT ? (T) : KT - 1;                                                      \
+    if ((T) < KT) {                                                                                  \
+        const int t_ = (T);                                                                          \
         _Pragma("unroll") for (int q = 0; q < A_F4; ++q)                                             \
             RA[q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + t_ * BK);                              \
         _Pragma("unroll") for (int q = 0; q < W_F4; ++q) RW[q] = reinterpret_cast<const f32x4*>(w_ptr[q])[(int64_t)t_ * KS * 64]; \
