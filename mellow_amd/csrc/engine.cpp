@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -157,6 +158,12 @@ struct mellow_engine {
 
     // graph
     bool use_graph = true;
+    // fp8 GEMM mode (BASELINE config 5): every packed weight with KP % 64 == 0 also gets a P8 copy + per-row scales,
+    // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
+    bool fp8 = false;
+    struct Fp8W { uint8_t* w8; float* scale; };
+    std::unordered_map<const float*, Fp8W> fp8_w;
+    Buf a8, a8_scale;     // quantised A operand of the GEMM in flight (bytes / floats, carved from float buffers)
     hipGraphExec_t step_exec = nullptr;
     int step_exec_B = -1, step_exec_Tmax = -1;
     int32_t* graph_out_tokens = nullptr;
@@ -489,6 +496,15 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(d0));
     if (d1) HIPCHK(hipFree(d1));
+    if (e->fp8 && p.KP % 64 == 0) {
+        float *w8f = nullptr, *sc = nullptr;
+        CHK(dev_alloc(e, &w8f, ((size_t)p.NP * p.KP + 3) / 4));
+        CHK(dev_alloc(e, &sc, (size_t)p.NP));
+        launch_pack_fp8(p.p, p.NP, p.KP, reinterpret_cast<uint8_t*>(w8f), sc, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->fp8_w[p.p] = {reinterpret_cast<uint8_t*>(w8f), sc};
+    }
     *out = p;
     return 0;
 }
@@ -729,6 +745,23 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
 
 // ---- GEMM wrappers -------------------------------------------------------------------------------------------------------
 static int run_gemm(mellow_engine* e, const GemmArgs& a) {
+    if (e->fp8 && a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
+        auto it = e->fp8_w.find(a.Wp);
+        if (it != e->fp8_w.end()) {
+            // quantise the activation rows, then the fp8 MFMA GEMM (same epilogue); profiled as one launch of the family
+            const int64_t lda8 = (a.K + 63) / 64 * 64;
+            CHK(ensure(e, e->a8, ((size_t)a.M * lda8 + 3) / 4));
+            CHK(ensure(e, e->a8_scale, (size_t)a.M));
+            GemmArgs g = a;
+            g.A8 = reinterpret_cast<const uint8_t*>(e->a8.p); g.lda8 = lda8; g.a_scale = e->a8_scale.p;
+            g.W8 = it->second.w8; g.w_scale = it->second.scale;
+            ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+            ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 100;
+            launch_quant_rows(a.A, a.lda, a.M, a.K, reinterpret_cast<uint8_t*>(e->a8.p), lda8, e->a8_scale.p, e->stream);
+            launch_gemm_fp8(g, e->stream);
+            return 0;
+        }
+    }
     ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
     ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi;
     launch_gemm(a, e->stream);
@@ -1328,6 +1361,58 @@ int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, flo
     hipFree(A); hipFree(W); hipFree(Cc);
     return 0;
 }
+// one fp8 GEMM C[M][N] = A[M][K] . W[N][K]^T on host data (quantise rows, pack + quantise weight, fp8 MFMA GEMM,
+// plain epilogue) and, optionally, its average time: the quantisation parity tap of include/mellow_hip.h
+int mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C_out, int iters,
+                        float* ms_out) {
+    if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 4) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const int NP = rup(N, 128);
+    float *dA = nullptr, *dW = nullptr, *dWp = nullptr, *dC = nullptr, *dsa = nullptr, *dsw = nullptr;
+    uint8_t *dA8 = nullptr, *dW8 = nullptr;
+    HIPCHK(hipMalloc(&dA, (size_t)M * K * 4));
+    HIPCHK(hipMalloc(&dW, (size_t)N * K * 4));
+    HIPCHK(hipMalloc(&dWp, (size_t)NP * K * 4));
+    HIPCHK(hipMalloc(&dC, (size_t)M * N * 4));
+    HIPCHK(hipMalloc(&dsa, (size_t)M * 4));
+    HIPCHK(hipMalloc(&dsw, (size_t)NP * 4));
+    HIPCHK(hipMalloc(&dA8, (size_t)M * K));
+    HIPCHK(hipMalloc(&dW8, (size_t)NP * K));
+    HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dW, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    launch_pack_weight(dW, N, K, K, dWp, NP, K, s);
+    launch_pack_fp8(dWp, NP, K, dW8, dsw, s);
+    GemmArgs g;
+    g.A = dA; g.lda = K; g.M = M; g.K = K; g.Wp = dWp; g.Nw = N; g.N = N; g.C = dC; g.ldc = N;
+    g.A8 = dA8; g.lda8 = K; g.a_scale = dsa; g.W8 = dW8; g.w_scale = dsw;
+    launch_quant_rows(dA, K, M, K, dA8, K, dsa, s);
+    launch_gemm_fp8(g, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    if (C_out) HIPCHK(hipMemcpy(C_out, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (ms_out && iters > 0) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        float ms_q = 0.f, ms_g = 0.f;
+        HIPCHK(hipEventRecord(a, s));
+        for (int i = 0; i < iters; ++i) launch_quant_rows(dA, K, M, K, dA8, K, dsa, s);
+        HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms_q, a, b));
+        HIPCHK(hipEventRecord(a, s));
+        for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, s);
+        HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms_g, a, b));
+        ms_out[0] = ms_q / iters;
+        ms_out[1] = ms_g / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    hipFree(dA); hipFree(dW); hipFree(dWp); hipFree(dC); hipFree(dsa); hipFree(dsw); hipFree(dA8); hipFree(dW8);
+    return 0;
+}
 // developer instrumentation (not part of the public header): one CSV line per profiled launch
 int mellow_dev_prof_dump(mellow_engine_t* e, const char* path) {
     if (!e || !path) return fail("bad argument");
@@ -1360,6 +1445,13 @@ int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
         set_kernel_debug_buffer(nullptr);
         set_gemm_debug_buffer(nullptr);
     }
+    return 0;
+}
+int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
+    if (!e) return fail("null engine");
+    if (e->finalized) return fail("precision must be chosen before mellow_engine_finalize");
+    if (mode != MELLOW_PRECISION_F32 && mode != MELLOW_PRECISION_FP8) return fail("unknown precision mode %d", mode);
+    e->fp8 = mode == MELLOW_PRECISION_FP8;
     return 0;
 }
 int mellow_set_graph(mellow_engine_t* e, int on) {

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace mellow {
@@ -216,112 +217,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
         g_kdbg[62] = __builtin_amdgcn_s_getreg(0xf804);    // HW_REG_HW_ID bits 15:0
     }
 #endif
-    // ---- epilogue: lane owns row m_local = lane&31 of each m-tile, columns 8g + 4h + (0..3) ----------
-    const int h = lane >> 5;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
-        if (m >= g.M) continue;
-        if constexpr (EPI == EPI_LINEAR) {
-            int64_t crow = m;
-            if (g.crow_map) crow = (int64_t)(m / g.rows_in) * g.rows_out + g.crow_map[m % g.rows_in];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int col = pn * BN + wn * 64 + ni * 32 + 8 * gq + 4 * h;
-                    if (col >= g.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * gq + j];
-                    if (g.bias) {
-                        const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
-                    if (g.act == ACT_GELU) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                    } else if (g.act == ACT_SIGMOID) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]);
-                    }
-                    if (g.resid) {
-                        const float4 r = *reinterpret_cast<const float4*>(g.resid + crow * g.ldr + col);
-                        v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
-                    }
-                    *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        } else {
-            // pair epilogues: n-tile 2*wn holds the first half of the pair, 2*wn+1 the second
-            const int P = pn * WN + wn;  // 64-column group index
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int i0 = 8 * gq + 4 * h;  // 0..31 within the pair
-                float x1[4], x2[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { x1[j] = acc[0][mi][4 * gq + j]; x2[j] = acc[1][mi][4 * gq + j]; }
-                if constexpr (EPI == EPI_POWER) {
-                    // re^2 + im^2 with separate roundings, like torch's real**2 + imag**2
-                    const int col = P * 32 + i0;
-                    if (col >= g.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fmul_rn(x1[j], x1[j]), __fmul_rn(x2[j], x2[j]));
-                    *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_SWIGLU) {
-                    const int col = P * 32 + i0;
-                    if (col >= g.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = __fmul_rn(siluf_(x1[j]), x2[j]);
-                    *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_LOGMEL) {
-                    // not a pair epilogue: both tiles are plain mel columns
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const int col = P * 64 + ni * 32 + i0;
-                        if (col >= g.N) continue;
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float x = ni == 0 ? x1[j] : x2[j];
-                            x = fmaxf(x, 1e-10f);
-                            x = __fmul_rn(10.0f, log10f(x));
-                            if (g.apply_bn) x = __fadd_rn(__fmul_rn(x, g.bn_alpha[col + j]), g.bn_beta[col + j]);
-                            v[j] = x;
-                        }
-                        *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                } else if constexpr (EPI == EPI_QKV_ROPE) {
-                    // P = head slot: [0,q_heads) query heads, then kv_heads key heads, then kv_heads value heads
-                    const int b = m / g.T, t = m % g.T;
-                    if (P < g.q_heads + g.kv_heads) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(g.rope_cos + (int64_t)t * 32 + i0);
-                        const float4 s4 = *reinterpret_cast<const float4*>(g.rope_sin + (int64_t)t * 32 + i0);
-                        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
-                        const float sn[4] = {s4.x, s4.y, s4.z, s4.w};
-                        float o1[4], o2[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // q*cos + rotate_half(q)*sin, products rounded separately (HF apply_rotary_pos_emb)
-                            o1[j] = __fadd_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(-x2[j], sn[j]));
-                            o2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
-                        }
-                        float* dst;
-                        if (P < g.q_heads) dst = g.q_out + (int64_t)m * (g.q_heads * 64) + P * 64;
-                        else dst = g.k_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
-                        *reinterpret_cast<float4*>(dst + i0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-                        *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-                    } else if (P < g.q_heads + 2 * g.kv_heads) {
-                        float* dst = g.v_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads - g.kv_heads)) * g.Tmax + t) * 64;
-                        *reinterpret_cast<float4*>(dst + i0) = make_float4(x1[0], x1[1], x1[2], x1[3]);
-                        *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(x2[0], x2[1], x2[2], x2[3]);
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
 
 template <int WM, int WN, int EPI, int BK>

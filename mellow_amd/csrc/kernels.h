@@ -58,8 +58,21 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
+    // fp8 mode (gemm_fp8.hip): both operands e4m3, fp32 accumulate, C = (A8 . W8^T) * a_scale[m] * w_scale[n] (+epilogue)
+    const uint8_t* A8 = nullptr;      // row-major [M][lda8] bytes, lda8 = K rounded up to 64
+    int64_t lda8 = 0;
+    const float* a_scale = nullptr;   // [M] per-row dequantisation factor (row amax / 448)
+    const uint8_t* W8 = nullptr;      // P8-layout weight
+    const float* w_scale = nullptr;   // [roundup(Nw,128)] per packed weight row
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
+// ---- fp8 (e4m3) GEMM path: BASELINE config 5 (gemm_fp8.hip) -------------------------------------------------
+// P8-layout of a weight: [n/32][k/32][lane][16 B], lane = (n%32) + 32*kh; the 16 bytes are the two A operands of
+// v_mfma_f32_32x32x16_fp8_fp8 for k = 32s + 8kh + (0..7) and k = 32s + 16 + 8kh + (0..7).
+void launch_quant_rows(const float* A, int64_t lda, int M, int K, uint8_t* A8, int64_t lda8, float* a_scale, hipStream_t s);
+// from an fp32 P-layout weight (NP x KP, already padded / pair-interleaved) to P8 + per-row scales
+void launch_pack_fp8(const float* Wp, int NP, int KP, uint8_t* W8, float* w_scale, hipStream_t s);
+void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, a_mode == A_PLAIN
 double gemm_flops(const GemmArgs& a);
 
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------

@@ -72,12 +72,14 @@ def load_library(path: Optional[str] = None):
         "mellow_argmax": (ci, [vp, vp, ci, vp]),
         "mellow_debug_enable_taps": (ci, [vp, ci]),
         "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
+        "mellow_debug_gemm_fp8": (ci, [vp, vp, ci, ci, vp, ci, vp, ci, vp]),
         "mellow_prof_enable": (ci, [vp, ci]),
         "mellow_prof_reset": (ci, [vp]),
         "mellow_prof_num_families": (ci, []),
         "mellow_prof_family_name": (C.c_char_p, [ci]),
         "mellow_prof_get": (ci, [vp, ci, P(i64), P(C.c_double), P(C.c_double), P(C.c_double)]),
         "mellow_last_phase_ms": (ci, [vp, P(cf), P(cf), P(cf)]),
+        "mellow_engine_set_precision": (ci, [vp, ci]),
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
         "mellow_host_pack_weight": (ci, [P(cf), ci, ci, ci, P(cf), i64]),
@@ -100,7 +102,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms",
-    "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
+    "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
 )
 
 
@@ -120,7 +122,8 @@ def _ptr(t: torch.Tensor) -> C.c_void_p:
 class Engine:
     """One engine per device.  Inputs/outputs are torch tensors on that device (plumbing only)."""
 
-    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 1024):
+    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 1024,
+                 precision: str = "f32"):
         self.lib = load_library()
         if self.lib.mellow_device_count() <= 0:
             raise EngineError("no HIP device visible: the Mellow engine needs an MI355X (no CPU fallback)")
@@ -139,6 +142,12 @@ class Engine:
         self._chk(self.lib.mellow_engine_create(C.byref(cfg), self.device, C.byref(h)))
         self.h = h
         self.finalized = False
+        # "f32": exact fp32 MFMA GEMMs (default; the parity mode).  "fp8": BASELINE config 5, e4m3 GEMMs in the encoder's
+        # Swin linears and LM prefill (fp32 accumulate; decode and front-end stay fp32) -- not bit-exact.
+        if precision not in ("f32", "fp8"):
+            raise ValueError(f"unknown precision {precision!r}")
+        self.precision = precision
+        self._chk(self.lib.mellow_engine_set_precision(self.h, 1 if precision == "fp8" else 0))
 
     # ---- errors ------------------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -252,6 +261,18 @@ class Engine:
         out = torch.empty((l.shape[0],), dtype=torch.int32, device=self.tdev)
         self._chk(self.lib.mellow_argmax(self.h, _ptr(l), l.shape[0], _ptr(out)))
         return out
+
+    def debug_gemm_fp8(self, A: torch.Tensor, W: torch.Tensor, iters: int = 0):
+        """fp8 mode quantisation tap: (C = A . W^T through the e4m3 GEMM, (quant_ms, gemm_ms) or None); host tensors."""
+        A = A.detach().cpu().contiguous().float()
+        W = W.detach().cpu().contiguous().float()
+        (M, K), (N, K2) = A.shape, W.shape
+        assert K == K2
+        out = torch.empty((M, N), dtype=torch.float32)
+        ms = (C.c_float * 2)()
+        self._chk(self.lib.mellow_debug_gemm_fp8(self.h, C.c_void_p(A.data_ptr()), M, K, C.c_void_p(W.data_ptr()), N,
+                                                 C.c_void_p(out.data_ptr()), int(iters), ms if iters > 0 else None))
+        return out, ((ms[0], ms[1]) if iters > 0 else None)
 
     def enable_taps(self, on: bool = True):
         self._chk(self.lib.mellow_debug_enable_taps(self.h, 1 if on else 0))

@@ -363,3 +363,63 @@ def test_pipelined_contexts_give_identical_tokens(engine, synth_sd):
     for (a1, a2, ids), res in zip(batches, got):
         want, *_ = engine.generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
         assert np.array_equal(res[0], want)
+
+
+# ---- BASELINE config 5: fp8 (e4m3) GEMM mode --------------------------------------------------------------------
+def _quant_rows_e4m3(x):
+    amax = x.abs().amax(dim=1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+    return (x * inv).to(torch.float8_e4m3fn).to(torch.float32), scale
+
+
+def test_fp8_gemm_matches_quantised_emulation(engine):
+    """The fp8 GEMM == exact products of the SAME e4m3 operands (per-row scales, RNE) accumulated in fp32.
+    Tolerance: fp32 accumulation-order noise (1e-4 of max) plus the rare element whose scaled value sits on a rounding
+    tie and lands one e4m3 step apart (bounded by 2e-3 of max); the quantisation itself costs ~4e-2 vs the exact product."""
+    torch.manual_seed(1)
+    for M, N, K in ((70, 36, 64), (389, 576, 576), (300, 960, 1536)):
+        A = torch.randn(M, K) * (0.2 + 3 * torch.rand(M, 1))
+        W = torch.randn(N, K) * 0.05 * (1 + torch.rand(N, 1))
+        A[3] = 0.0                                                     # an all-zero row must quantise to zeros
+        got, _ = engine.debug_gemm_fp8(A, W)
+        Aq, sa = _quant_rows_e4m3(A)
+        Wq, sw = _quant_rows_e4m3(W)
+        ref = (Aq.double() @ Wq.double().T) * sa.double() * sw.double().T
+        exact = A.double() @ W.double().T
+        scale = float(ref.abs().max())
+        d = (got.double() - ref).abs()
+        assert torch.isfinite(got).all()
+        assert float(d.max()) <= 2e-3 * scale, (M, N, K, float(d.max()), scale)
+        assert float((d > 1e-4 * scale).double().mean()) < 1e-3          # almost every element is accumulation noise only
+        assert float(got[3].abs().max()) == 0.0
+        assert float((ref - exact).abs().max()) > 5e-3 * scale            # sanity: the emulation really is quantised
+
+
+def test_fp8_mode_end_to_end(synth_sd, engine, golden_dir):
+    """precision="fp8": e4m3 GEMMs in the Swin linears and LM prefill, everything else fp32.  Not bit-exact by design;
+    the test pins (a) determinism, (b) bounded error against the fp32 engine, (c) that the fp32 engine is untouched.
+    Measured on the synthetic (random-weight, un-trained) checkpoint: prefix rel-rms 5e-2, prefill logits rel-rms 0.17,
+    first-token agreement ~0.6 -- a random network amplifies 3-bit-mantissa noise; see DESIGN.md §9."""
+    from mellow_amd.engine import Engine
+    e8 = Engine(device=0, max_positions=1024, precision="fp8")
+    e8.load_state_dict(synth_sd)
+    B = 16
+    a1, a2, ids = synth.make_batch(B)
+    p32 = engine.prefix(a1, a2, ids)
+    p8 = e8.prefix(a1, a2, ids)
+    rel = float((p8 - p32).pow(2).mean().sqrt() / p32.pow(2).mean().sqrt())
+    assert torch.isfinite(p8).all() and 1e-4 < rel < 0.15, rel
+    l32 = engine.lm_prefill(p32, reserve=2).cpu()
+    l8 = e8.lm_prefill(p32, reserve=2).cpu()
+    rel_l = float((l8 - l32).pow(2).mean().sqrt() / l32.pow(2).mean().sqrt())
+    assert torch.isfinite(l8).all() and rel_l < 0.5, rel_l
+    t8a, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
+    t8b, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t8a, t8b)                                      # deterministic
+    t32, *_ = engine.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
+    agree = float((t8a[:, 0] == t32[:, 0]).mean())
+    assert agree >= 0.25, agree                                          # far above chance (1/49152)
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
+    e8.close()
