@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="examples per GPU")
     ap.add_argument("--max-len", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("f32", "fp8"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "fp8", "f32x3"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) or fp8 (BASELINE config 5: e4m3 GEMMs in the encoder's "
                          "Swin linears and LM prefill; a different metric line, not comparable with the headline)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -181,10 +181,14 @@ def main():
         peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "audio-pair responses/sec (v0 167M, 2x10s clips, max_len=64, greedy)" +
-                      (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else ""),
+                      (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else "") +
+                      (" [experimental f32x3 mode: fp32 GEMMs as exact 3-way bf16 splits on the bf16 MFMA pipe]"
+                       if args.precision == "f32x3" else ""),
             "value": round(value, 2), "unit": "responses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8_e4m3 GEMMs (Swin linears + LM prefill), f32 accumulate; decode/front-end f32" if fp8 else "f32",
+            "dtype": ("fp8_e4m3 GEMMs (Swin linears + LM prefill), f32 accumulate; decode/front-end f32" if fp8 else
+                      "f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per k-step, f32 accumulate)"
+                      if args.precision == "f32x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"v0 167M, batch {B}/GPU, 2x10s 32kHz synthetic clips + 16-token prompts, max_len={L}, "
                                    f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",

@@ -128,6 +128,10 @@ int  mellow_debug_tap(mellow_engine_t* e, const char* name, float* out, int64_t 
  * quantised per row and W per row to OCP e4m3 (scale = amax / 448, round to nearest even), exact products, fp32
  * accumulation.  K % 64 == 0, N % 4 == 0.  iters > 0 and ms2 != NULL: ms2[0] / ms2[1] receive the average time of the
  * quantisation pass / of the GEMM in milliseconds.  Works on any engine (finalised or not). */
+/* Same for the fp32 paths: mode 0 = the exact fp32 MFMA kernel, 9 (or 6) = the bf16x3 split kernel with all nine (the six
+ * largest) partial products.  K % 32 == 0. */
+int  mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C,
+                           int iters, float* ms2);
 int  mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C,
                            int iters, float* ms2);
 
@@ -154,6 +158,10 @@ int         mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* pr
  *   layers and the decode step stay fp32.  Not bit-exact: report token agreement.  No reference counterpart. */
 #define MELLOW_PRECISION_F32 0
 #define MELLOW_PRECISION_FP8 1
+#define MELLOW_PRECISION_F32X3 2   /* experimental: fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY
+                                      into three bf16 terms, the six largest partial products (the rest is < 2^-23 |a*b|) are
+                                      accumulated in fp32: fp32-accurate (error vs fp64 measured <= the fp32 MFMA kernel's),
+                                      not bit-identical to MELLOW_PRECISION_F32 (different summation order) */
 int         mellow_engine_set_precision(mellow_engine_t* e, int mode);
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

@@ -161,6 +161,8 @@ struct mellow_engine {
     // fp8 GEMM mode (BASELINE config 5): every packed weight with KP % 64 == 0 also gets a P8 copy + per-row scales,
     // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
     bool fp8 = false;
+    int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
+    std::unordered_map<const float*, void*> bf_w;   // fp32 packed pointer -> PB copy
     struct Fp8W { uint8_t* w8; float* scale; };
     std::unordered_map<const float*, Fp8W> fp8_w;
     Buf a8, a8_scale;     // quantised A operand of the GEMM in flight (bytes / floats, carved from float buffers)
@@ -496,6 +498,14 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(d0));
     if (d1) HIPCHK(hipFree(d1));
+    if (e->f32x3_terms && p.KP % 16 == 0) {
+        float* pb = nullptr;
+        CHK(dev_alloc(e, &pb, ((size_t)p.NP * p.KP * 6 + 3) / 4));
+        launch_pack_bf16x3(p.p, p.NP, p.KP, pb, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->bf_w[p.p] = pb;
+    }
     if (e->fp8 && p.KP % 64 == 0) {
         float *w8f = nullptr, *sc = nullptr;
         CHK(dev_alloc(e, &w8f, ((size_t)p.NP * p.KP + 3) / 4));
@@ -745,6 +755,21 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
 
 // ---- GEMM wrappers -------------------------------------------------------------------------------------------------------
 static int run_gemm(mellow_engine* e, const GemmArgs& a) {
+    if (e->f32x3_terms && a.a_mode == A_PLAIN && a.K % 16 == 0 &&
+        (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
+        auto it = e->bf_w.find(a.Wp);
+        if (it != e->bf_w.end()) {
+            CHK(ensure(e, e->a8, ((size_t)a.M * a.K * 6 + 3) / 4));
+            GemmArgs g = a;
+            g.A8 = reinterpret_cast<const uint8_t*>(e->a8.p); g.lda8 = (int64_t)3 * (a.K >> 3);
+            g.W8 = reinterpret_cast<const uint8_t*>(it->second);
+            ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+            ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 200;
+            launch_split_rows(a.A, a.lda, a.M, a.K, e->a8.p, e->stream);
+            launch_gemm_bf16x3(g, e->f32x3_terms, e->stream);
+            return 0;
+        }
+    }
     if (e->fp8 && a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
         auto it = e->fp8_w.find(a.Wp);
         if (it != e->fp8_w.end()) {
@@ -1361,6 +1386,60 @@ int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, flo
     hipFree(A); hipFree(W); hipFree(Cc);
     return 0;
 }
+// one fp32 GEMM C[M][N] = A[M][K] . W[N][K]^T on host data through the exact fp32 MFMA kernel (mode 0) or the bf16x3 split
+// kernel with 6 / 9 partial products (mode 6 / 9): the accuracy tap of include/mellow_hip.h
+int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C_out,
+                          int iters, float* ms2) {
+    if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return fail("bad argument");
+    if (mode != 0 && mode != 6 && mode != 9) return fail("mode must be 0, 6 or 9");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const int NP = rup(N, 128);
+    float *dA = nullptr, *dW = nullptr, *dWp = nullptr, *dC = nullptr;
+    void *dA3 = nullptr, *dPB = nullptr;
+    HIPCHK(hipMalloc(&dA, (size_t)M * K * 4));
+    HIPCHK(hipMalloc(&dW, (size_t)N * K * 4));
+    HIPCHK(hipMalloc(&dWp, (size_t)NP * K * 4));
+    HIPCHK(hipMalloc(&dC, (size_t)M * N * 4));
+    HIPCHK(hipMalloc(&dA3, (size_t)M * K * 6));
+    HIPCHK(hipMalloc(&dPB, (size_t)NP * K * 6));
+    HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dW, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    launch_pack_weight(dW, N, K, K, dWp, NP, K, s);
+    launch_pack_bf16x3(dWp, NP, K, dPB, s);
+    GemmArgs g;
+    g.A = dA; g.lda = K; g.M = M; g.K = K; g.Wp = dWp; g.Nw = N; g.N = N; g.C = dC; g.ldc = N;
+    g.A8 = reinterpret_cast<const uint8_t*>(dA3); g.lda8 = (int64_t)3 * (K >> 3); g.W8 = reinterpret_cast<const uint8_t*>(dPB);
+    auto run = [&](bool pre, bool main) {
+        if (mode == 0) { if (main) launch_gemm(g, s); }
+        else { if (pre) launch_split_rows(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3(g, mode, s); }
+    };
+    run(true, true);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    if (C_out) HIPCHK(hipMemcpy(C_out, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (ms2 && iters > 0) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        float m0 = 0.f, m1 = 0.f;
+        HIPCHK(hipEventRecord(a, s));
+        for (int i = 0; i < iters; ++i) run(true, false);
+        HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&m0, a, b));
+        HIPCHK(hipEventRecord(a, s));
+        for (int i = 0; i < iters; ++i) run(false, true);
+        HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&m1, a, b));
+        ms2[0] = m0 / iters;
+        ms2[1] = m1 / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    hipFree(dA); hipFree(dW); hipFree(dWp); hipFree(dC); hipFree(dA3); hipFree(dPB);
+    return 0;
+}
 // one fp8 GEMM C[M][N] = A[M][K] . W[N][K]^T on host data (quantise rows, pack + quantise weight, fp8 MFMA GEMM,
 // plain epilogue) and, optionally, its average time: the quantisation parity tap of include/mellow_hip.h
 int mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C_out, int iters,
@@ -1450,8 +1529,17 @@ int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
 int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     if (!e) return fail("null engine");
     if (e->finalized) return fail("precision must be chosen before mellow_engine_finalize");
-    if (mode != MELLOW_PRECISION_F32 && mode != MELLOW_PRECISION_FP8) return fail("unknown precision mode %d", mode);
+    if (mode != MELLOW_PRECISION_F32 && mode != MELLOW_PRECISION_FP8 && mode != MELLOW_PRECISION_F32X3)
+        return fail("unknown precision mode %d", mode);
     e->fp8 = mode == MELLOW_PRECISION_FP8;
+    e->f32x3_terms = 0;
+    if (mode == MELLOW_PRECISION_F32X3) {
+        // six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64
+        // product is identical to the nine-term form and slightly below the fp32 MFMA kernel's (tools/f32x3_check.py).
+        // Developer knob: MELLOW_F32X3_TERMS=9 keeps every partial product.
+        const char* t = getenv("MELLOW_F32X3_TERMS");
+        e->f32x3_terms = (t && atoi(t) == 9) ? 9 : 6;
+    }
     return 0;
 }
 int mellow_set_graph(mellow_engine_t* e, int on) {

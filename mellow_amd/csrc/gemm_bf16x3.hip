@@ -1,0 +1,203 @@
+// fp32 GEMM on the bf16 matrix pipe by exact operand splitting ("bf16x3"): every fp32 operand value is the exact sum of
+// three bf16 numbers, a = a1 + a2 + a3 (8 + 8 + 8 significand bits), so a*b = sum_ij ai*bj with every partial product
+// exact in fp32; the products run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32 accumulation.
+//   TERMS = 9: all partial products -> each a*b is exact before accumulation (what the fp32 MFMA also guarantees);
+//   TERMS = 6: drops a2*b3, a3*b2, a3*b3 (< 2^-23 |a*b| in total), the order of one fp32 rounding.
+// Accumulation order differs from the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32, so results are fp32-accurate, not
+// bit-identical to that kernel; tools/f32x3_check.py measures all three against an fp64 product.
+// Opt-in (MELLOW_PRECISION_F32X3); the default and every parity claim stay on the exact fp32 MFMA kernel.
+//
+//   split_rows   A fp32 [M][K] -> A3 [M][K/8][3][8 bf16]                           (one wave per row, before each GEMM)
+//   pack_bf16x3  W fp32 P-layout -> PB [n/32][k/16][3][lane][8 bf16]               (once per tensor at load time)
+//   gemm         128 x 128 tile, 4 waves, one k16 step per stage (12 KiB per operand), double-buffered LDS in
+//                fragment order, 12 ds_read_b128 feed 4 x TERMS MFMAs; shared epilogues (gemm_epilogue.h).
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace mellow {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+    h = static_cast<__bf16>(a);                       // round to nearest even (v_cvt_pk_bf16_f32)
+    const float r1 = a - static_cast<float>(h);       // exact
+    m = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(m);      // exact, at most 8 significant bits
+    l = static_cast<__bf16>(r2);                      // exact
+}
+__device__ __forceinline__ void split8(const float (&v)[8], i32x4& p0, i32x4& p1, i32x4& p2) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        split3(v[j], a, b, c);
+        h[j] = a; m[j] = b; l[j] = c;
+    }
+    p0 = __builtin_bit_cast(i32x4, h);
+    p1 = __builtin_bit_cast(i32x4, m);
+    p2 = __builtin_bit_cast(i32x4, l);
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ A, int64_t lda, int M, int K,
+                                                         i32x4* __restrict__ A3, int64_t ld3 /* i32x4 per row = 3 K/8 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const f32x4* row = reinterpret_cast<const f32x4*>(A + (int64_t)m * lda);
+    i32x4* out = A3 + (int64_t)m * ld3;
+    const int K8 = K >> 3;
+    for (int g8 = lane; g8 < K8; g8 += 64) {
+        const f32x4 x = row[2 * g8], y = row[2 * g8 + 1];
+        const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        i32x4 p0, p1, p2;
+        split8(v, p0, p1, p2);
+        out[3 * g8 + 0] = p0;
+        out[3 * g8 + 1] = p1;
+        out[3 * g8 + 2] = p2;
+    }
+}
+void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s) {
+    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, lda, M, K, reinterpret_cast<i32x4*>(A3),
+                       (int64_t)3 * (K >> 3));
+}
+
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ Wp, int NP, int KP, i32x4* __restrict__ PB) {
+    const int K16 = KP >> 4, K8 = KP >> 3;
+    const int64_t total = (int64_t)(NP >> 5) * K16 * 64;            // one thread per (n-tile, k16, lane): 3 x 16 bytes
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int64_t tile = i >> 6;
+        const int s16 = (int)(tile % K16), nt = (int)(tile / K16);
+        const int n = nt * 32 + (lane & 31), k0 = s16 * 16 + (lane >> 5) * 8;
+        float v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int k = k0 + b;
+            v[b] = Wp[(((int64_t)(n >> 5) * K8 + (k >> 3)) * 64 + (n & 31) + 32 * ((k >> 2) & 1)) * 4 + (k & 3)];
+        }
+        i32x4 p0, p1, p2;
+        split8(v, p0, p1, p2);
+        i32x4* o = PB + (tile * 3) * 64 + lane;
+        o[0] = p0; o[64] = p1; o[128] = p2;
+    }
+}
+void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s) {
+    const int64_t total = (int64_t)(NP >> 5) * (KP >> 4) * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(blocks), dim3(256), 0, s, Wp, NP, KP, reinterpret_cast<i32x4*>(PB));
+}
+
+struct GemmBDev {
+    GemmArgs a;
+    int gm, gn;
+};
+
+#define MELLOW_BF(W, A, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, A), ACC, 0, 0, 0);
+
+template <int EPI, int TERMS>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmBDev p) {
+    constexpr int BM = 128, BN = 128, WN = 2;
+    constexpr int STAGE = 3 * 4 * 64;                  // 16-byte slots per operand per stage: [piece][tile][lane]
+    __shared__ __attribute__((aligned(16))) i32x4 As[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) i32x4 Ws[2 * STAGE];
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
+    const int pm = L / p.gn, pn = L % p.gn;
+    const int K16 = g.K >> 4;
+    const bool wave_active = (pn * BN + wn * 64) < g.Nw;
+    const i32x4* A3 = reinterpret_cast<const i32x4*>(g.A8);
+    const i32x4* PB = reinterpret_cast<const i32x4*>(g.W8);
+    const int64_t ld3 = g.lda8;                        // i32x4 per row of A3
+
+    const i32x4* a_ptr[3];
+    int a_lds[3];
+    const i32x4* w_ptr[3];
+    int w_lds[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int c = q * 256 + tid;
+        const int row = c / 6, j = c % 6;              // 6 chunks per row per stage: (k8 half, piece)
+        int m = pm * BM + row;
+        m = m < g.M ? m : g.M - 1;
+        a_ptr[q] = A3 + (int64_t)m * ld3 + j;
+        a_lds[q] = ((j % 3) * 4 + (row >> 5)) * 64 + (row & 31) + 32 * (j / 3);
+        const int ntl = c / 192, rem = c % 192;        // W: [n-tile][piece][lane] per k16
+        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * K16) * 192 + rem;
+        w_lds[q] = ((rem >> 6) * 4 + ntl) * 64 + (rem & 63);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    i32x4 ra[3], rw[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ra[q] = a_ptr[q][0]; rw[q] = w_ptr[q][0]; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { As[a_lds[q]] = ra[q]; Ws[w_lds[q]] = rw[q]; }
+    __syncthreads();
+    for (int kt = 0; kt < K16; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = kt + 1 < K16 ? kt + 1 : kt;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { ra[q] = a_ptr[q][(int64_t)ktn * 6]; rw[q] = w_ptr[q][(int64_t)ktn * 192]; }
+        if (wave_active) {
+            const i32x4* Ac = As + cur * STAGE + (2 * wm) * 64 + lane;
+            const i32x4* Wc = Ws + cur * STAGE + (2 * wn) * 64 + lane;
+            i32x4 a[2][3], w[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) { a[t][pc] = Ac[(pc * 4 + t) * 64]; w[t][pc] = Wc[(pc * 4 + t) * 64]; }
+            // smallest partial products first
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if (TERMS == 9) {
+                        MELLOW_BF(w[ni][2], a[mi][2], acc[ni][mi])
+                        MELLOW_BF(w[ni][2], a[mi][1], acc[ni][mi])
+                        MELLOW_BF(w[ni][1], a[mi][2], acc[ni][mi])
+                    }
+                    MELLOW_BF(w[ni][2], a[mi][0], acc[ni][mi])
+                    MELLOW_BF(w[ni][0], a[mi][2], acc[ni][mi])
+                    MELLOW_BF(w[ni][1], a[mi][1], acc[ni][mi])
+                    MELLOW_BF(w[ni][1], a[mi][0], acc[ni][mi])
+                    MELLOW_BF(w[ni][0], a[mi][1], acc[ni][mi])
+                    MELLOW_BF(w[ni][0], a[mi][0], acc[ni][mi])
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { As[(cur ^ 1) * STAGE + a_lds[q]] = ra[q]; Ws[(cur ^ 1) * STAGE + w_lds[q]] = rw[q]; }
+        __syncthreads();
+    }
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
+}
+#undef MELLOW_BF
+
+template <int EPI>
+static void launchb(const GemmArgs& a, int terms, hipStream_t s) {
+    GemmBDev d;
+    d.a = a;
+    d.gm = (a.M + 127) / 128;
+    d.gn = (a.Nw + 127) / 128;
+    if (terms == 6) hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 6>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 9>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
+}
+void launch_gemm_bf16x3(const GemmArgs& a, int terms, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_LINEAR: launchb<EPI_LINEAR>(a, terms, s); break;
+        case EPI_SWIGLU: launchb<EPI_SWIGLU>(a, terms, s); break;
+        case EPI_QKV_ROPE: launchb<EPI_QKV_ROPE>(a, terms, s); break;
+        default: break;
+    }
+}
+
+}  // namespace mellow

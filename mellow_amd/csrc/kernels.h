@@ -73,6 +73,11 @@ void launch_quant_rows(const float* A, int64_t lda, int M, int K, uint8_t* A8, i
 // from an fp32 P-layout weight (NP x KP, already padded / pair-interleaved) to P8 + per-row scales
 void launch_pack_fp8(const float* Wp, int NP, int KP, uint8_t* W8, float* w_scale, hipStream_t s);
 void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, a_mode == A_PLAIN
+// ---- fp32 GEMM on the bf16 matrix pipe by exact 3-way operand splitting (gemm_bf16x3.hip) ----------------------
+// operands travel in GemmArgs::A8 (A3 [M][K/8][3][8 bf16], lda8 = 16-byte units per row = 3 K/8) and GemmArgs::W8 (PB)
+void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s);
+void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s);
+void launch_gemm_bf16x3(const GemmArgs& a, int terms /* 6 or 9 partial products */, hipStream_t s);   // K % 16 == 0
 double gemm_flops(const GemmArgs& a);
 
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------

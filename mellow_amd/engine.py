@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None):
         "mellow_debug_enable_taps": (ci, [vp, ci]),
         "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
         "mellow_debug_gemm_fp8": (ci, [vp, vp, ci, ci, vp, ci, vp, ci, vp]),
+        "mellow_debug_gemm_f32": (ci, [vp, ci, vp, ci, ci, vp, ci, vp, ci, vp]),
         "mellow_prof_enable": (ci, [vp, ci]),
         "mellow_prof_reset": (ci, [vp]),
         "mellow_prof_num_families": (ci, []),
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms",
-    "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
+    "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
 )
 
 
@@ -144,10 +145,10 @@ class Engine:
         self.finalized = False
         # "f32": exact fp32 MFMA GEMMs (default; the parity mode).  "fp8": BASELINE config 5, e4m3 GEMMs in the encoder's
         # Swin linears and LM prefill (fp32 accumulate; decode and front-end stay fp32) -- not bit-exact.
-        if precision not in ("f32", "fp8"):
+        if precision not in ("f32", "fp8", "f32x3"):
             raise ValueError(f"unknown precision {precision!r}")
         self.precision = precision
-        self._chk(self.lib.mellow_engine_set_precision(self.h, 1 if precision == "fp8" else 0))
+        self._chk(self.lib.mellow_engine_set_precision(self.h, {"f32": 0, "fp8": 1, "f32x3": 2}[precision]))
 
     # ---- errors ------------------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -261,6 +262,18 @@ class Engine:
         out = torch.empty((l.shape[0],), dtype=torch.int32, device=self.tdev)
         self._chk(self.lib.mellow_argmax(self.h, _ptr(l), l.shape[0], _ptr(out)))
         return out
+
+    def debug_gemm_f32(self, A: torch.Tensor, W: torch.Tensor, mode: int = 0, iters: int = 0):
+        """C = A . W^T through the exact fp32 MFMA kernel (mode 0) or the bf16x3 split kernel (mode 9 / 6); host tensors."""
+        A = A.detach().cpu().contiguous().float()
+        W = W.detach().cpu().contiguous().float()
+        (M, K), (N, K2) = A.shape, W.shape
+        assert K == K2
+        out = torch.empty((M, N), dtype=torch.float32)
+        ms = (C.c_float * 2)()
+        self._chk(self.lib.mellow_debug_gemm_f32(self.h, int(mode), C.c_void_p(A.data_ptr()), M, K, C.c_void_p(W.data_ptr()), N,
+                                                 C.c_void_p(out.data_ptr()), int(iters), ms if iters > 0 else None))
+        return out, ((ms[0], ms[1]) if iters > 0 else None)
 
     def debug_gemm_fp8(self, A: torch.Tensor, W: torch.Tensor, iters: int = 0):
         """fp8 mode quantisation tap: (C = A . W^T through the e4m3 GEMM, (quant_ms, gemm_ms) or None); host tensors."""

@@ -423,3 +423,31 @@ def test_fp8_mode_end_to_end(synth_sd, engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
     e8.close()
+
+
+def test_f32x3_mode_is_fp32_accurate(engine, synth_sd, golden_dir):
+    """Experimental precision="f32x3": fp32 GEMMs run as exact 3-way bf16 operand splits on the bf16 MFMA pipe.
+    (a) one GEMM against an fp64 product: no less accurate than the exact fp32 MFMA kernel (x1.25 slack on max / rms);
+    (b) end to end: greedy tokens identical to the fp32 engine and to the reference goldens, logits within the same
+        3e-3 tolerance the fp32 path is held to."""
+    from mellow_amd.engine import Engine
+    torch.manual_seed(2)
+    A = torch.randn(389, 576) * (0.2 + 3 * torch.rand(389, 1))
+    W = torch.randn(576, 576) * 0.05
+    exact = A.double() @ W.double().T
+    e_mfma = (engine.debug_gemm_f32(A, W, mode=0)[0].double() - exact).abs()
+    for mode in (6, 9):
+        e_x3 = (engine.debug_gemm_f32(A, W, mode=mode)[0].double() - exact).abs()
+        assert float(e_x3.max()) <= 1.25 * float(e_mfma.max()) and float(e_x3.pow(2).mean()) <= 1.25 ** 2 * float(e_mfma.pow(2).mean())
+    e3 = Engine(device=0, max_positions=1024, precision="f32x3")
+    e3.load_state_dict(synth_sd)
+    a1, a2, ids = synth.make_batch(4)
+    t3, *_ = e3.generate(a1, a2, ids, max_len=12, stop_id=0, ignore_stop=True)
+    t0, *_ = engine.generate(a1, a2, ids, max_len=12, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t3, t0)
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    assert np.array_equal(t3[:2], g["tokens"])
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    prefix = torch.from_numpy(e["prefix"])
+    _close(e3.lm_prefill(prefix, reserve=2), engine.lm_prefill(prefix, reserve=2), rel=0, atol=3e-3, name="f32x3 prefill logits")
+    e3.close()
