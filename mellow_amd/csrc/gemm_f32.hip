@@ -36,6 +36,13 @@ struct GemmDev {
 __device__ uint64_t* g_kdbg = nullptr;
 void set_gemm_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &p, sizeof(p)); }
 
+// pin a wave-uniform pointer in scalar registers so that loads through it use the `saddr + 32-bit voffset` form
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
 template <int WM, int WN, int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -71,7 +78,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     const bool wave_active = (pn * BN + wn * 64) < g.Nw;
 
     // ---- per-thread load descriptors -------------------------------------------------------------
-    const float* a_ptr[A_F4];
+    // global addresses = wave-uniform base (SGPR pair, advanced per k-tile on the scalar unit) + a 32-bit per-lane byte
+    // offset: the loads use the saddr form and the loop carries no 64-bit vector address arithmetic
+    uint32_t a_off[A_F4];
     int a_lds[A_F4];
 #pragma unroll
     for (int q = 0; q < A_F4; ++q) {
@@ -84,16 +93,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
         int64_t off;
         if (g.a_mode == A_FRAMES) off = (int64_t)(m / g.fpc) * g.clip_stride + (int64_t)(m % g.fpc) * g.hop;
         else off = (int64_t)m * g.lda;
-        a_ptr[q] = g.A + off + chunk * 4;
+        a_off[q] = (uint32_t)((off + chunk * 4) * (int64_t)sizeof(float));
         a_lds[q] = ((chunk >> 1) * MT + (row >> 5)) * 64 + (row & 31) + 32 * (chunk & 1);
     }
-    const float4* w_ptr[W_F4];
+    uint32_t w_off[W_F4];
     int w_lds[W_F4];
 #pragma unroll
     for (int q = 0; q < W_F4; ++q) {
         const int idx = q * 256 + tid;
         const int ln = idx & 63, k8 = (idx >> 6) % KS, ntl = idx / (64 * KS);
-        w_ptr[q] = reinterpret_cast<const float4*>(g.Wp) + ((int64_t)(nt0 + ntl) * K8 + k8) * 64 + ln;
+        w_off[q] = (uint32_t)((((int64_t)ntl * K8 + k8) * 64 + ln) * 16);
         w_lds[q] = (k8 * NTB + ntl) * 64 + ln;
     }
 
@@ -114,13 +123,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     // that every array index is static.  Prefetches past the last k-tile are skipped (uniform branch).
     // native vector type, not HIP's float4 struct: struct copies become llvm.memcpy through a private alloca that the
     // compiler did not promote for this loop shape (every prefetch went through scratch memory)
+    const char* a_base = reinterpret_cast<const char*>(g.A);
+    const char* w_base = reinterpret_cast<const char*>(g.Wp) + (size_t)nt0 * K8 * 64 * 16;
     f32x4 ra0[A_F4], rw0[W_F4], ra1[A_F4], rw1[W_F4];
 #define MELLOW_GLOAD(RA, RW, T)                                                                      \
     if ((T) < KT) {                                                                                  \
         const int t_ = (T);                                                                          \
+        const char* ab_ = sgpr_ptr(a_base + (size_t)t_ * (BK * 4));                                  \
+        const char* wb_ = sgpr_ptr(w_base + (size_t)t_ * (KS * 64 * 16));                            \
         _Pragma("unroll") for (int q = 0; q < A_F4; ++q)                                             \
-            RA[q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + t_ * BK);                              \
-        _Pragma("unroll") for (int q = 0; q < W_F4; ++q) RW[q] = reinterpret_cast<const f32x4*>(w_ptr[q])[(int64_t)t_ * KS * 64]; \
+            RA[q] = *reinterpret_cast<const f32x4*>(ab_ + a_off[q]);                                      \
+        _Pragma("unroll") for (int q = 0; q < W_F4; ++q)                                             \
+            RW[q] = *reinterpret_cast<const f32x4*>(wb_ + w_off[q]);                                      \
     }
 #define MELLOW_LSTORE(RA, RW, STAGE)                                                                 \
     {                                                                                                \
