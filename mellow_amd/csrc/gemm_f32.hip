@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
         const f32x4* Ac = reinterpret_cast<const f32x4*>(As + (STAGE) * A_STAGE + (2 * wm) * 64 + lane); \
         const f32x4* Wc = reinterpret_cast<const f32x4*>(Ws + (STAGE) * W_STAGE + (2 * wn) * 64 + lane); \
         f32x4 xa0 = Ac[0], xa1 = Ac[64], xw0 = Wc[0], xw1 = Wc[64];                                  \
+        __builtin_amdgcn_s_setprio(2);                                                               \
         _Pragma("unroll") for (int k8 = 0; k8 < KS; k8 += 2) {                                       \
             const f32x4 ya0 = Ac[((k8 + 1) * MT) * 64], ya1 = Ac[((k8 + 1) * MT + 1) * 64];          \
             const f32x4 yw0 = Wc[((k8 + 1) * NTB) * 64], yw1 = Wc[((k8 + 1) * NTB + 1) * 64];        \
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
             __builtin_amdgcn_sched_barrier(0);                                                       \
             MELLOW_MFMA16(yw0, yw1, ya0, ya1)                                                        \
         }                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                               \
     } else {                                                                                         \
         STORE                                                                                        \
     }
