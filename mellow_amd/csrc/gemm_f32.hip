@@ -255,13 +255,9 @@ static void launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI>
 static void launch_epi(const GemmArgs& a, hipStream_t s) {
-    // pick the block shape that wastes fewer padded columns: 128x128 or 256x64
-    const int w128 = (a.Nw + 127) / 128 * 128, w64 = (a.Nw + 63) / 64 * 64;
-    static const int force = getenv("MELLOW_GEMM_TILE") ? atoi(getenv("MELLOW_GEMM_TILE")) : 0;   // dev knob: 1 = always 128x128, 2 = old rule
-    const bool tall = force == 1 ? false : (force == 2 ? (w64 < w128 && a.M >= 256) : (a.Nw <= 64 && a.M >= 256));
-    static const int bk = getenv("MELLOW_GEMM_BK") ? atoi(getenv("MELLOW_GEMM_BK")) : 32;   // dev knob
-    if (tall) launch_cfg<4, 1, EPI, 32>(a, s);
-    else if (bk == 16) launch_cfg<2, 2, EPI, 16>(a, s);
+    // 128x128 everywhere except the narrow outputs (mel: 64 columns), where 256x64 wastes no padded columns.
+    // (Measured and not kept: 256x64 whenever it pads less, and a 16-wide k-tile with 32 KB of LDS -- both slower.)
+    if (a.Nw <= 64 && a.M >= 256) launch_cfg<4, 1, EPI, 32>(a, s);
     else launch_cfg<2, 2, EPI, 32>(a, s);
 }
 
