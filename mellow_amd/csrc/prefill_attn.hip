@@ -1,8 +1,8 @@
 // Causal GQA flash attention for LM prefill in exact fp32 on v_mfma_f32_32x32x2_f32 (replaces the
 // eager/sdpa attention inside transformers' LlamaAttention for the 389-token prefix).
 //
-// One workgroup = (example b, kv head g, 32-query tile); its 3 waves are the 3 query heads that share
-// kv head g (GQA 9q/3kv), so each K/V tile is staged in LDS once for three heads.
+// One workgroup = (example b, kv head g, 32-query tile): 3 compute waves = the 3 query heads that share kv head g
+// (GQA 9q/3kv), so each K/V tile is staged in LDS once for three heads, plus a 4th loader wave that stages the next tile.
 //
 // Register-resident softmax without any cross-lane shuffles of P: the score tile is computed
 // TRANSPOSED, S^T = K Q^T (K tile = MFMA A operand, Q = B operand), so a lane owns ONE query column and
@@ -20,47 +20,65 @@ constexpr int PA_KT_STRIDE = 33;   // transposed K tile row stride (floats): con
 // softmax weights on the hardware exp2 (x <= 0; ~1e-6 relative, inside fp32 summation-order noise); exp(-inf) = 0
 __device__ __forceinline__ float pa_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-__global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __restrict__ q,
+__global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __restrict__ q,
                                                                 const float* __restrict__ k_cache,
                                                                 const float* __restrict__ v_cache,
                                                                 float* __restrict__ o, int T, int Tmax) {
-    __shared__ __attribute__((aligned(16))) float Kt[64 * PA_KT_STRIDE];   // [d][key]
-    __shared__ __attribute__((aligned(16))) float Vs[32 * 64];             // [key][d]
+    // wave specialisation: waves 0..2 = the three query heads of kv head g (MFMA + softmax), wave 3 = loader: it owns
+    // the global -> LDS staging (K transposed, V row-major) of the NEXT key tile into the other LDS stage while the
+    // compute waves work, so they carry no staging registers (148 VGPRs -> three workgroups per CU) and never wait
+    // for a load.  (Pairing a long and a short query tile per workgroup was measured too: slower, the hardware's
+    // dynamic dispatch of 1248 unequal workgroups balances better than 672 equal ones.)
+    __shared__ __attribute__((aligned(16))) float Kt[2][64 * PA_KT_STRIDE];   // [stage][d][key]
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * 64];             // [stage][key][d]
     // heavy tiles first: a query tile qt walks qt+1 key tiles (causal), so the long workgroups must not start last
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+
+    if (wave == 3) {
+        // ---------------- loader wave: 512 float4 per operand per tile = 8 + 8 per lane ----------------
+        f32x4 pk[8], pv[8];
+        auto fetch = [&](int kt) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = lane + 64 * j, key = i >> 4, quad = i & 15;
+                int t = kt * 32 + key;
+                t = t < T ? t : T - 1;
+                pk[j] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + quad * 4);
+                pv[j] = *reinterpret_cast<const f32x4*>(vpage + (int64_t)t * 64 + quad * 4);
+            }
+        };
+        auto stage = [&](int st) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = lane + 64 * j, key = i >> 4, quad = i & 15;
+                Kt[st][(quad * 4 + 0) * PA_KT_STRIDE + key] = pk[j].x;
+                Kt[st][(quad * 4 + 1) * PA_KT_STRIDE + key] = pk[j].y;
+                Kt[st][(quad * 4 + 2) * PA_KT_STRIDE + key] = pk[j].z;
+                Kt[st][(quad * 4 + 3) * PA_KT_STRIDE + key] = pk[j].w;
+                *reinterpret_cast<f32x4*>(&Vs[st][key * 64 + quad * 4]) = pv[j];
+            }
+        };
+        fetch(0);
+        stage(0);
+        fetch(qt >= 1 ? 1 : 0);
+        __syncthreads();                                   // tile 0 visible
+        for (int kt = 0; kt <= qt; ++kt) {
+            stage((kt + 1) & 1);                           // tile kt+1 (or a harmless re-read past the end) -> other stage
+            fetch(kt + 2 <= qt ? kt + 2 : qt);
+            __syncthreads();                               // compute waves are done with stage kt & 1; stage (kt+1) & 1 is visible
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
     const int hq = 3 * g + wave;
     const int h = lane >> 5, ql = lane & 31;
     const int q0 = qt * 32;
     const int qi = q0 + ql;                              // this lane's query position
     const int qc = qi < T ? qi : T - 1;
-    const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
-    const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
-
-    // staging roles: 512 float4 per operand tile over 192 threads = 3 slots per thread (the last one partly idle;
-    // idle slots re-read float4 0 and skip the LDS store)
-    int st_key[3], st_quad[3];
-    bool st_on[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int i = tid + 192 * j;
-        st_on[j] = i < 512;
-        const int ic = st_on[j] ? i : 0;
-        st_key[j] = ic >> 4;
-        st_quad[j] = ic & 15;
-    }
-    f32x4 pk[3], pv[3];                                  // next tile, in flight while the current one is computed
-    auto fetch = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            int t = kt * 32 + st_key[j];
-            t = t < T ? t : T - 1;
-            pk[j] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + st_quad[j] * 4);
-            pv[j] = *reinterpret_cast<const f32x4*>(vpage + (int64_t)t * 64 + st_quad[j] * 4);
-        }
-    };
-    fetch(0);
-
     // Q as MFMA B operand: step s holds Q[query][2s + h], pre-scaled by 1/8 (exact)
     float qreg[32];
     {
@@ -72,32 +90,19 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
+    __syncthreads();                                       // tile 0 staged by the loader
 
     for (int kt = 0; kt <= qt; ++kt) {
         const int k0 = kt * 32;
-        __syncthreads();
-        // stage K (transposed) and V (row-major) from the prefetch registers
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (st_on[j]) {
-                const int key = st_key[j], quad = st_quad[j];
-                Kt[(quad * 4 + 0) * PA_KT_STRIDE + key] = pk[j].x;
-                Kt[(quad * 4 + 1) * PA_KT_STRIDE + key] = pk[j].y;
-                Kt[(quad * 4 + 2) * PA_KT_STRIDE + key] = pk[j].z;
-                Kt[(quad * 4 + 3) * PA_KT_STRIDE + key] = pk[j].w;
-                *reinterpret_cast<f32x4*>(Vs + key * 64 + quad * 4) = pv[j];
-            }
-        }
-        __syncthreads();
-        fetch(kt < qt ? kt + 1 : kt);                    // unconditional (the last iteration re-reads its own tile)
-
+        const float* Kc = Kt[kt & 1];
+        const float* Vc = Vs[kt & 1];
         // S^T[key][query] = sum_d K[key][d] Q[query][d]
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const float a = Kt[(2 * s + h) * PA_KT_STRIDE + ql];
+            const float a = Kc[(2 * s + h) * PA_KT_STRIDE + ql];
             S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
         }
         // lane: query ql, keys k0 + (r&3) + 8(r>>2) + 4h
@@ -127,11 +132,12 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float a0 = Vs[key * 64 + ql];
-            const float a1 = Vs[key * 64 + 32 + ql];
+            const float a0 = Vc[key * 64 + ql];
+            const float a1 = Vc[key * 64 + 32 + ql];
             O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p[r], O0, 0, 0, 0);
             O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p[r], O1, 0, 0, 0);
         }
+        __syncthreads();                                   // done with stage kt & 1; the next tile is visible
     }
     if (qi < T) {
         const float inv = 1.0f / l_run;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(192) void prefill_attention_kernel(const float* __r
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
                               int Tmax, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(192), 0, s, q, k_cache, v_cache, o, T, Tmax);
+    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, T, Tmax);
 }
 
 }  // namespace mellow
