@@ -112,10 +112,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # developer overrides used to exercise the multi-process plumbing on a 1-GPU box (2 ranks sharing GPU 0 over gloo);
+    # the driver's runs use neither: one rank per GPU, backend "nccl" (= RCCL over xGMI)
+    backend = os.environ.get("MELLOW_BENCH_BACKEND", "nccl")
+    if "MELLOW_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MELLOW_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; running on {n_gpus} GPU(s)", file=sys.stderr)
@@ -125,6 +133,7 @@ def main():
     dev = local_rank if world > 1 else 0
     eng = Engine(device=dev, max_positions=1024, precision=args.precision)     # raises if libmellow_hip.so or the GPU is missing
     eng.load_state_dict(synth.make_state_dict(0))
+    comm_dev = eng.tdev if backend == "nccl" else torch.device("cpu")      # where the collectives' buffers live
     B, L = args.batch, args.max_len
     a1, a2, ids = synth.make_batch(B, first=rank * B)
     a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
@@ -133,7 +142,7 @@ def main():
         toks, lens, steps, ftm = eng.generate(a1d, a2d, idsd, max_len=L, top_p=0.8, temperature=1.0, stop_id=0,
                                               ignore_stop=True)
         if world > 1:   # the path's single exchange: all-gather of the token ids over RCCL/xGMI
-            mdist.gather_tokens(toks, lens, world * B, L, device=eng.tdev)
+            mdist.gather_tokens(toks, lens, world * B, L, device=comm_dev)
         return ftm
 
     for _ in range(args.warmup):
@@ -148,7 +157,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     phases = eng.last_phase_ms()
