@@ -451,3 +451,23 @@ def test_f32x3_mode_is_fp32_accurate(engine, synth_sd, golden_dir):
     prefix = torch.from_numpy(e["prefix"])
     _close(e3.lm_prefill(prefix, reserve=2), engine.lm_prefill(prefix, reserve=2), rel=0, atol=3e-3, name="f32x3 prefill logits")
     e3.close()
+
+
+def test_degenerate_audio_matches_oracle(engine, synth_sd):
+    """Edge inputs of the front-end: digital silence (log-mel floor 1e-10 -> -100 dB everywhere), a full-scale square
+    wave, and a single impulse.  The prefix must stay finite and equal the oracle's."""
+    from oracle import mellow_oracle as O
+    n = 320000
+    sil = np.zeros(n, dtype=np.float32)
+    sq = np.where((np.arange(n) // 40) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    imp = np.zeros(n, dtype=np.float32)
+    imp[12345] = 1.0
+    a1 = np.stack([sil, sq, imp])
+    a2 = np.stack([imp, sil, sq])
+    ids = np.stack([synth.make_prompt_ids(i) for i in range(3)])
+    got = engine.prefix(a1, a2, ids).cpu()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        want = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids))
+    assert torch.isfinite(got).all()
+    _close(got, want, rel=5e-4, name="prefix of degenerate audio")
