@@ -124,12 +124,12 @@ int  mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* toke
 int  mellow_debug_enable_taps(mellow_engine_t* e, int on);
 int  mellow_debug_tap(mellow_engine_t* e, const char* name, float* out, int64_t capacity, int64_t* numel);
 
-/* One GEMM of the fp8 mode on HOST data, for the quantisation parity test: C[M][N] = A[M][K] . W[N][K]^T with A
- * quantised per row and W per row to OCP e4m3 (scale = amax / 448, round to nearest even), exact products, fp32
- * accumulation.  K % 64 == 0, N % 4 == 0.  iters > 0 and ms2 != NULL: ms2[0] / ms2[1] receive the average time of the
- * quantisation pass / of the GEMM in milliseconds.  Works on any engine (finalised or not). */
-/* Same for the fp32 paths: mode 0 = the exact fp32 MFMA kernel, 9 (or 6) = the bf16x3 split kernel with all nine (the six
- * largest) partial products.  K % 32 == 0. */
+/* Numeric taps on HOST data (work on any engine, finalised or not): C[M][N] = A[M][K] . W[N][K]^T through one GEMM kernel.
+ * iters > 0 and ms2 != NULL: ms2[0] / ms2[1] receive the average milliseconds of the operand pre-pass / of the GEMM.
+ *   mellow_debug_gemm_f32: mode 0 = the exact fp32 MFMA kernel (no pre-pass), 9 / 6 = the bf16x3 split kernel with all nine /
+ *     the six largest partial products (MELLOW_PRECISION_F32X3).  K % 32 == 0, N % 4 == 0.
+ *   mellow_debug_gemm_fp8: the MELLOW_PRECISION_FP8 GEMM -- A quantised per row and W per row to OCP e4m3 (scale =
+ *     amax / 448, round to nearest even), exact products, fp32 accumulation.  K % 64 == 0, N % 4 == 0. */
 int  mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C,
                            int iters, float* ms2);
 int  mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C,
@@ -151,19 +151,21 @@ int         mellow_prof_get(mellow_engine_t* e, int i, int64_t* launches, double
  * decode loop; milliseconds */
 int         mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms, float* decode_ms);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
-/* Numeric mode of the dense GEMMs of the encoder (Swin linears) and of LM prefill; call before mellow_engine_finalize.
+int         mellow_set_graph(mellow_engine_t* e, int on);
+
+/* ---- numeric mode of the dense GEMMs of the encoder (Swin linears) and of LM prefill; call before the first
+ *      mellow_engine_load_tensor.  The reference has no counterpart (fp32 ATen matmuls throughout).
  *   MELLOW_PRECISION_F32 (default): exact fp32 on v_mfma_f32_32x32x2_f32 -- the mode every parity claim refers to.
  *   MELLOW_PRECISION_FP8: BASELINE config 5 -- OCP e4m3 weights (per-output-channel scale) and activations (per-row
- *   scale, quantised on the fly), fp32 accumulate on v_mfma_f32_32x32x16_fp8_fp8.  Front-end (STFT, mel), K % 64 != 0
- *   layers and the decode step stay fp32.  Not bit-exact: report token agreement.  No reference counterpart. */
+ *     scale, quantised on the fly), fp32 accumulate on v_mfma_f32_32x32x16_fp8_fp8.  Front-end (STFT, mel), K % 64 != 0
+ *     layers and the decode step stay fp32.  Not bit-exact: report token agreement.
+ *   MELLOW_PRECISION_F32X3 (experimental): fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into
+ *     three bf16 terms, the six largest partial products (the rest is < 2^-23 |a*b|) are accumulated in fp32:
+ *     fp32-accurate (error against fp64 measured <= the fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32. */
 #define MELLOW_PRECISION_F32 0
 #define MELLOW_PRECISION_FP8 1
-#define MELLOW_PRECISION_F32X3 2   /* experimental: fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY
-                                      into three bf16 terms, the six largest partial products (the rest is < 2^-23 |a*b|) are
-                                      accumulated in fp32: fp32-accurate (error vs fp64 measured <= the fp32 MFMA kernel's),
-                                      not bit-identical to MELLOW_PRECISION_F32 (different summation order) */
+#define MELLOW_PRECISION_F32X3 2
 int         mellow_engine_set_precision(mellow_engine_t* e, int mode);
-int         mellow_set_graph(mellow_engine_t* e, int on);
 
 /* ---- host-only helpers (callable without a GPU; used by CPU tests) -------------------------------- */
 /* token permutation of a Swin block: out[m] = source token (h*R+w) feeding window-order row m, for
