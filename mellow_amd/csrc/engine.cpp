@@ -167,6 +167,7 @@ struct mellow_engine {
     std::unordered_map<const float*, Fp8W> fp8_w;
     Buf a8, a8_scale;     // quantised A operand of the GEMM in flight (bytes / floats, carved from float buffers)
     hipGraphExec_t step_exec = nullptr;
+    hipGraphExec_t step_exec8 = nullptr;      // the same step captured 8 times in a row (the step is position-independent)
     int step_exec_B = -1, step_exec_Tmax = -1;
     int32_t* graph_out_tokens = nullptr;
     int graph_max_len = -1, graph_stop = -1;
@@ -414,6 +415,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->step_exec) hipGraphExecDestroy(e->step_exec);
+    if (e->step_exec8) hipGraphExecDestroy(e->step_exec8);
     for (void* p : e->allocs) hipFree(p);
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
@@ -972,6 +974,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         HIPCHK(hipMemsetAsync(e->kcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
         HIPCHK(hipMemsetAsync(e->vcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
     }
     {
         // carve the decode-step buffers out of one arena (all sizes are multiples of 64 floats = 256 B)
@@ -992,6 +995,8 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
             // padded batch rows are computed but never read back; start from finite values
             HIPCHK(hipMemsetAsync(e->dec.p, 0, off * sizeof(float), e->stream));
             if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+            if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
+        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         }
         float* p = e->dec.p;
         DecArgs& a = e->da;
@@ -1266,6 +1271,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tokens != out_tokens ||
                   e->graph_max_len != max_len || e->graph_stop != stop_id)) {
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         hipGraph_t gr = nullptr;
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_decode_layers(e, B, &rec);
@@ -1274,16 +1280,34 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
         HIPCHK(hipGraphInstantiate(&e->step_exec, gr, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(gr));
+        // eight consecutive steps as ONE graph: the step reads its position from the device word, so a replay of the
+        // same kernel sequence IS the next step; one launch per 8 steps removes the host/CP hand-over between graphs
+        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
+        if (max_len > 8) {
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int rc8 = 0;
+            for (int k = 0; k < 8 && !rc8; ++k) rc8 = enqueue_decode_layers(e, B, &rec);
+            hipError_t ce8 = hipStreamEndCapture(s, &gr);
+            if (rc8) return rc8;
+            if (ce8 != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce8));
+            HIPCHK(hipGraphInstantiate(&e->step_exec8, gr, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(gr));
+        }
         e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tokens = out_tokens; e->graph_max_len = max_len;
         e->graph_stop = stop_id;
     }
     int steps_done = 1;   // token 0 came from the prefill
-    for (int i = 1; i < max_len; ++i) {
-        if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
+    for (int i = 1; i < max_len;) {
+        // stop checks happen after steps 7, 15, ... (i % 8 == 7): an 8-step graph may run from i to i+7 when it ends on one
+        const bool eight = graph && e->step_exec8 && i + 8 <= max_len && (ignore_stop || (i + 7) % 8 == 7);
+        const int n_adv = eight ? 8 : 1;
+        if (eight) HIPCHK(hipGraphLaunch(e->step_exec8, s));
+        else if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
         else CHK(enqueue_decode_layers(e, B, &rec));
-        e->cur_pos += 1;
-        steps_done = i + 1;
-        if (!ignore_stop && (i % 8) == 7) {
+        i += n_adv;
+        e->cur_pos += n_adv;
+        steps_done = i;
+        if (!ignore_stop && ((i - 1) % 8) == 7) {
             int32_t seen = 0;
             HIPCHK(hipMemcpyAsync(&seen, e->d_nseen, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
