@@ -80,20 +80,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     // ---- per-thread load descriptors -------------------------------------------------------------
     // global addresses = wave-uniform base (SGPR pair, advanced per k-tile on the scalar unit) + a 32-bit per-lane byte
     // offset: the loads use the saddr form and the loop carries no 64-bit vector address arithmetic
+    // (offsets are relative to the workgroup's first row, so they stay far below 4 GiB however large the matrix is)
     uint32_t a_off[A_F4];
     int a_lds[A_F4];
+    auto row_off = [&](int m) -> int64_t {
+        m = m < g.M ? m : g.M - 1;
+        return g.a_mode == A_FRAMES ? (int64_t)(m / g.fpc) * g.clip_stride + (int64_t)(m % g.fpc) * g.hop : (int64_t)m * g.lda;
+    };
+    const int64_t a_row0 = row_off(pm * BM);            // monotonic in m for both addressing modes
 #pragma unroll
     for (int q = 0; q < A_F4; ++q) {
         const int idx = q * 256 + tid;
         // 8 consecutive lanes -> 8 rows (conflict-free 128 B LDS write), next lane bits -> the CH chunks of a row
         const int row = (idx / (8 * CH)) * 8 + (idx & 7);
         const int chunk = (idx >> 3) % CH;
-        int m = pm * BM + row;
-        m = m < g.M ? m : g.M - 1;
-        int64_t off;
-        if (g.a_mode == A_FRAMES) off = (int64_t)(m / g.fpc) * g.clip_stride + (int64_t)(m % g.fpc) * g.hop;
-        else off = (int64_t)m * g.lda;
-        a_off[q] = (uint32_t)((off + chunk * 4) * (int64_t)sizeof(float));
+        a_off[q] = (uint32_t)((row_off(pm * BM + row) - a_row0 + chunk * 4) * (int64_t)sizeof(float));
         a_lds[q] = ((chunk >> 1) * MT + (row >> 5)) * 64 + (row & 31) + 32 * (chunk & 1);
     }
     uint32_t w_off[W_F4];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev p) {
     // that every array index is static.  Prefetches past the last k-tile are skipped (uniform branch).
     // native vector type, not HIP's float4 struct: struct copies become llvm.memcpy through a private alloca that the
     // compiler did not promote for this loop shape (every prefetch went through scratch memory)
-    const char* a_base = reinterpret_cast<const char*>(g.A);
+    const char* a_base = reinterpret_cast<const char*>(g.A + a_row0);
     const char* w_base = reinterpret_cast<const char*>(g.Wp) + (size_t)nt0 * K8 * 64 * 16;
     f32x4 ra0[A_F4], rw0[W_F4], ra1[A_F4], rw1[W_F4];
 #define MELLOW_GLOAD(RA, RW, T)                                                                      \

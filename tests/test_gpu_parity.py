@@ -471,3 +471,17 @@ def test_degenerate_audio_matches_oracle(engine, synth_sd):
         want = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids))
     assert torch.isfinite(got).all()
     _close(got, want, rel=5e-4, name="prefix of degenerate audio")
+
+
+def test_encoder_activations_beyond_4gib(engine):
+    """BASELINE config 4 scale: 98 clips of 30 s = 686 encoder crops, so the stage-0 MLP activation (2.8 M rows x 384 floats)
+    is 4.3 GB -- past the reach of a 32-bit byte offset.  Rows are batch-independent, so the last clip (whose rows lie beyond
+    the 4 GiB line) and the first must equal the same clips encoded alone, exactly."""
+    n = 30 * spec.SAMPLE_RATE
+    base = [synth.make_clip(i, n) for i in range(4)]
+    wav = np.stack([base[i % 4] for i in range(98)])
+    big = engine.encode(wav).cpu()
+    assert torch.isfinite(big).all()
+    for idx in (0, 97):
+        alone = engine.encode(wav[idx:idx + 1]).cpu()
+        assert torch.equal(big[idx], alone[0]), idx
