@@ -335,15 +335,16 @@ def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
 
 
 def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
-    """BASELINE configs[3] shape at reduced batch: 2 x 30 s clips (7 encoder crops per clip), max_len=128.
+    """BASELINE configs[3] at its full size: batch 64, 2 x 30 s clips (7 encoder crops per clip = 896 crops), max_len=128.
     Rows are batch-independent (exact), the prefix equals the oracle's, and the tokens extend the oracle's first steps."""
     from oracle import mellow_oracle as O
-    B, L = 6, 128
+    B, L = 64, 128
     a1, a2, ids = synth.make_batch(B, n_samples=30 * spec.SAMPLE_RATE)
     t, lens, n, _ = engine.generate(a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
     assert t.shape == (B, L) and n == L
-    t1, *_ = engine.generate(a1[4:5], a2[4:5], ids[4:5], max_len=L, stop_id=0, ignore_stop=True)
-    assert np.array_equal(t1[0], t[4])
+    for r in (4, 63):
+        t1, *_ = engine.generate(a1[r:r + 1], a2[r:r + 1], ids[r:r + 1], max_len=L, stop_id=0, ignore_stop=True)
+        assert np.array_equal(t1[0], t[r]), r
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     with torch.no_grad():
         prefix = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1[:1]), torch.from_numpy(a2[:1]),
