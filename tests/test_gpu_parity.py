@@ -423,6 +423,12 @@ def test_fp8_mode_end_to_end(synth_sd, engine, golden_dir):
     assert agree >= 0.25, agree                                          # far above chance (1/49152)
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
+    # config 5's batch (128, max_len 64): per-row quantisation keeps rows batch-independent, so the first 16 rows of the
+    # big batch must equal the small batch exactly
+    a1b, a2b, idsb = synth.make_batch(128)
+    t128, _, n128, _ = e8.generate(a1b, a2b, idsb, max_len=64, stop_id=0, ignore_stop=True)
+    assert t128.shape == (128, 64) and n128 == 64 and (t128 >= 0).all() and (t128 < 49152).all()
+    assert np.array_equal(t128[:16, :8], t8a)
     e8.close()
 
 
