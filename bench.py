@@ -177,6 +177,18 @@ def main():
         ref_sem = {"value": round(n_ref * B / (time.perf_counter() - t1), 2), "unit": "responses/s", "passes": n_ref,
                    "steps_run": int(steps_run), "note": "stop id honoured (reference loop exit rule); synthetic weights never emit it"}
 
+    # ---- PCIe-inclusive rate: the same pass with the waveforms and prompt ids starting in (pageable) host memory ----
+    pcie = None
+    if rank == 0 and world == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_p = max(1, min(3, args.steps))
+        for _ in range(n_p):
+            eng.generate(eng._f32(a1), eng._f32(a2), eng._i32(ids), max_len=L, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
+        torch.cuda.synchronize()
+        pcie = {"value": round(n_p * B / (time.perf_counter() - t1), 2), "unit": "responses/s", "passes": n_p,
+                "note": f"host->device copy of 2 x {B} x 1.28 MB waveforms + ids inside the timed region (never the headline)"}
+
     # ---- roofline of the dominant kernel family, HIP events on the engine's stream over one more step ----
     eng.prof_enable(True)
     eng.prof_reset()
@@ -233,6 +245,8 @@ def main():
         }
         if ref_sem is not None:
             out["reference_semantics"] = ref_sem
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if n_gpus == 1 and args.inflight > 1:
             out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
         if n_gpus == 1 and not args.no_cpu_baseline:
