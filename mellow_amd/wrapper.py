@@ -140,8 +140,17 @@ class MellowWrapper:
 
     def preprocess_audio(self, audio_files, resample):
         """-> float32 (B, segment_seconds*sampling_rate) on the engine's device (reference wrapper.py:170-179)."""
-        tensors = [self.load_audio_into_tensor(f, self.args.data["segment_seconds"], resample).reshape(1, -1)
-                   for f in audio_files]
+        # files are independent: decode / resample / tile-or-crop on a thread pool (torch releases the GIL in the conv1d of
+        # the resampler); output order = input order.  The reference does this serially; its crop start is an unseeded
+        # `random` draw per file (wrapper.py:164), so the draw order carries no meaning.
+        def one(f):
+            return self.load_audio_into_tensor(f, self.args.data["segment_seconds"], resample).reshape(1, -1)
+        if len(audio_files) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(audio_files), os.cpu_count() or 1, 32)) as pool:
+                tensors = list(pool.map(one, audio_files))
+        else:
+            tensors = [one(f) for f in audio_files]
         return torch.cat(tensors, 0).to(self.model.tdev)
 
     def preprocess_text(self, prompts):
