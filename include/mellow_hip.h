@@ -115,6 +115,11 @@ int  mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, in
 /* A15 decode step: append embed_tokens(token_ids) (wrapper.py:237) at the next position and return the
  * new last-position logits.  token_ids dev i32 [B]; logits dev [B][vocab] (may be NULL). */
 int  mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* logits);
+/* A0 (host harness of the reference, wrapper.py:146 `torchaudio.transforms.Resample(sr, 32000)`) on the device:
+ * sinc-interpolation resampling with a Hann window, lowpass_filter_width 6, rolloff 0.99, gcd-reduced polyphase bank.
+ * wav dev [n][n_in] -> out dev [n][*n_out], *n_out = ceil(new_freq * n_in / orig_freq); out == NULL only queries *n_out. */
+int  mellow_resample(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_in, int orig_freq, int new_freq,
+                     float* out, int64_t out_capacity, int64_t* n_out);
 /* arg-max with first-index ties (torch.argmax, wrapper.py:232): logits dev [B][vocab] -> tokens dev i32 [B] */
 int  mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* tokens);
 

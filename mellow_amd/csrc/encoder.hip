@@ -368,6 +368,34 @@ void launch_crop_average(const float* in, int n, int n_crops, int64_t len, int64
     hipLaunchKernelGGL(crop_average_kernel, dim3(64, n), dim3(256), 0, s, in, n_crops, len, in_stride, out, out_stride);
 }
 
+// ---- host-harness helper A0 on the device: sinc-hann polyphase resampler (reference wrapper.py:146 ->
+// torchaudio.transforms.Resample defaults; host twin: mellow_amd/audio.py resample()).  out[c][f*new + p] =
+// sum_k x[c][f*orig + k - width] * wT[k][p], k < 2*width + orig, zero outside the clip; one thread per output sample,
+// the frame's threads share x (broadcast) and read wT rows coalesced.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t n_in, const float* __restrict__ wT,
+                                                       int orig, int nw, int klen, int width, float* __restrict__ out,
+                                                       int64_t n_out) {
+    const int c = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t f = o / nw;
+    const int p = (int)(o % nw);
+    const float* xc = x + (int64_t)c * n_in;
+    const int64_t base = f * orig - width;
+    float acc = 0.f;
+    for (int k = 0; k < klen; ++k) {
+        const int64_t t = base + k;
+        const float xv = (t >= 0 && t < n_in) ? xc[t] : 0.f;
+        acc = fmaf(xv, wT[(int64_t)k * nw + p], acc);
+    }
+    out[(int64_t)c * n_out + o] = acc;
+}
+void launch_resample(const float* x, int n_clips, int64_t n_in, const float* wT, int orig, int nw, int klen, int width,
+                     float* out, int64_t n_out, hipStream_t s) {
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256), n_clips), dim3(256), 0, s, x, n_in, wT, orig, nw,
+                       klen, width, out, n_out);
+}
+
 __global__ void gelu_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = gelu_erf(in[i]);

@@ -1229,6 +1229,48 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
     return 0;
 }
 
+// A0 on the device: torchaudio-style sinc_interp_hann resampling (lowpass_filter_width 6, rolloff 0.99), the polyphase bank
+// built exactly like mellow_amd/audio.py::_sinc_resample_kernel (float64, then cast to float32)
+int mellow_resample(mellow_engine_t* e, const float* wav, int n_clips, int64_t n_in, int orig_freq, int new_freq, float* out,
+                    int64_t out_capacity, int64_t* n_out) {
+    if (!e || !wav || n_clips <= 0 || n_in <= 0 || orig_freq <= 0 || new_freq <= 0) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    int a = orig_freq, b = new_freq;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int orig = orig_freq / a, nw = new_freq / a;
+    const int64_t target = (int64_t)((nw * n_in + orig - 1) / orig);       // ceil(new * length / orig)
+    if (n_out) *n_out = target;
+    if (!out) return 0;
+    if (out_capacity < target) return fail("resample output buffer too small");
+    const double PI = 3.14159265358979323846, lpw = 6.0, rolloff = 0.99;
+    const double base_freq = (orig < nw ? orig : nw) * rolloff;
+    const int width = (int)std::ceil(lpw * orig / base_freq);
+    const int klen = 2 * width + orig;
+    std::vector<float> wT((size_t)klen * nw);
+    const double scale = base_freq / orig;
+    for (int p = 0; p < nw; ++p)
+        for (int k = 0; k < klen; ++k) {
+            double t = (double)(-p) / nw + (double)(k - width) / orig;
+            t *= base_freq;
+            if (t < -lpw) t = -lpw;
+            if (t > lpw) t = lpw;
+            const double c = std::cos(t * PI / lpw / 2.0);
+            const double window = c * c;
+            t *= PI;
+            const double kern = t == 0.0 ? 1.0 : std::sin(t) / t;
+            wT[(size_t)k * nw + p] = (float)(kern * window * scale);
+        }
+    float* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, wT.size() * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(dw, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    // rows of `out` are `target` long: the kernel writes with stride n_out = target
+    launch_resample(wav, n_clips, n_in, dw, orig, nw, klen, width, out, target, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(dw));
+    return 0;
+}
+
 int mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* tokens) {
     if (!e || !logits || !tokens || B <= 0) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));

@@ -134,6 +134,9 @@ void set_kernel_debug_buffer(uint64_t* p);
 void set_gemm_debug_buffer(uint64_t* p);
 
 // ---- front-end ---------------------------------------------------------------------------------------
+// device twin of the host resampler (A0): wT = transposed polyphase bank [klen][nw]
+void launch_resample(const float* x, int n_clips, int64_t n_in, const float* wT, int orig, int nw, int klen, int width,
+                     float* out, int64_t n_out, hipStream_t s);
 void launch_reflect_pad(const float* wav, int n_clips, int64_t n_samples, float* out, int64_t padded_len, int pad,
                         hipStream_t s);
 // logmel_bn [n_src][src_frames][64] -> x0 [n_virtual][4096][96]; virtual clip v = src*n_crops + crop reads

@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None):
         "mellow_lm_prefill": (ci, [vp, vp, ci, ci, ci, vp]),
         "mellow_lm_decode_step": (ci, [vp, vp, vp]),
         "mellow_argmax": (ci, [vp, vp, ci, vp]),
+        "mellow_resample": (ci, [vp, vp, ci, i64, ci, ci, vp, i64, P(i64)]),
         "mellow_debug_enable_taps": (ci, [vp, ci]),
         "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
         "mellow_debug_gemm_fp8": (ci, [vp, vp, ci, ci, vp, ci, vp, ci, vp]),
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms",
-    "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
+    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
 )
 
 
@@ -261,6 +262,19 @@ class Engine:
         l = self._f32(logits)
         out = torch.empty((l.shape[0],), dtype=torch.int32, device=self.tdev)
         self._chk(self.lib.mellow_argmax(self.h, _ptr(l), l.shape[0], _ptr(out)))
+        return out
+
+    def resample(self, wav, orig_freq: int, new_freq: int) -> torch.Tensor:
+        """(n, n_in) -> (n, ceil(new*n_in/orig)) on the device: the A0 resampler (twin of mellow_amd.audio.resample)."""
+        w = self._f32(wav)
+        if w.dim() == 1:
+            w = w[None]
+        n, n_in = w.shape
+        n_out = C.c_int64(0)
+        self._chk(self.lib.mellow_resample(self.h, _ptr(w), n, n_in, int(orig_freq), int(new_freq), None, 0, C.byref(n_out)))
+        out = torch.empty((n, n_out.value), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_resample(self.h, _ptr(w), n, n_in, int(orig_freq), int(new_freq), _ptr(out), n_out.value,
+                                           C.byref(n_out)))
         return out
 
     def debug_gemm_f32(self, A: torch.Tensor, W: torch.Tensor, mode: int = 0, iters: int = 0):

@@ -139,7 +139,18 @@ class MellowWrapper:
         return load_audio_into_tensor(audio_path, audio_duration, self.args.data["sampling_rate"], resample)
 
     def preprocess_audio(self, audio_files, resample):
-        """-> float32 (B, segment_seconds*sampling_rate) on the engine's device (reference wrapper.py:170-179)."""
+        """-> float32 (B, segment_seconds*sampling_rate) on the engine's device (reference wrapper.py:170-179).
+        With MELLOW_DEVICE_RESAMPLE=1 the resampling runs on the GPU (mellow_resample, the device twin of audio.resample):
+        files are decoded on the host, resampled per file on the device, then tiled / cropped as in the reference."""
+        if resample and os.environ.get("MELLOW_DEVICE_RESAMPLE") == "1":
+            from .audio import fit_duration, load_wav
+            sr_t = self.args.data["sampling_rate"]
+            rows = []
+            for f in audio_files:
+                wav, sr = load_wav(str(f))
+                w = self.model.resample(wav, sr, sr_t) if sr != sr_t else wav.to(self.model.tdev)
+                rows.append(fit_duration(w.reshape(-1), self.args.data["segment_seconds"] * sr_t).to(torch.float32).reshape(1, -1))
+            return torch.cat(rows, 0).to(self.model.tdev)
         # files are independent: decode / resample / tile-or-crop on a thread pool (torch releases the GIL in the conv1d of
         # the resampler); output order = input order.  The reference does this serially; its crop start is an unseeded
         # `random` draw per file (wrapper.py:164), so the draw order carries no meaning.

@@ -492,3 +492,17 @@ def test_encoder_activations_beyond_4gib(engine):
     for idx in (0, 97):
         alone = engine.encode(wav[idx:idx + 1]).cpu()
         assert torch.equal(big[idx], alone[0]), idx
+
+
+def test_device_resampler_matches_host_twin(engine):
+    """mellow_resample (A0 on the device) == mellow_amd.audio.resample (the host restatement of torchaudio's
+    sinc_interp_hann defaults): 44.1 kHz -> 32 kHz and 48 kHz -> 32 kHz, odd lengths, two clips at once.
+    Tolerance: fp32 summation order of a 459-tap dot product."""
+    from mellow_amd import audio
+    rng = np.random.default_rng(9)
+    for sr, n in ((44100, 403604), (48000, 12345), (16000, 4000), (22050, 1)):
+        x = torch.from_numpy((rng.standard_normal((2, n)) * 0.3).astype(np.float32))
+        want = audio.resample(x, sr, 32000)
+        got = engine.resample(x, sr, 32000).cpu()
+        assert got.shape == want.shape, (sr, n, got.shape, want.shape)
+        assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (sr, n)
