@@ -39,6 +39,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Per-file flags.  VGPR-form MFMA: keep accumulators in architectural VGPRs (gfx950's register file is unified).  Without it
+# the compiler parks the accumulators of the bf16 / fp8 kernels in AGPRs and copies all 64 of them in and out of VGPRs every
+# loop iteration (v_accvgpr_read/write: as many VALU issue slots as the MFMAs themselves), and every `O *= alpha` of the
+# flash attention is a read-modify-write through copies.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FILE_FLAGS = {name: VGPR_FORM for name in os.environ.get("MELLOW_VGPR_FORM_FILES", "gemm_bf16x3.hip gemm_fp8.hip").split()}
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -55,7 +63,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         sp, op = job
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", op]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

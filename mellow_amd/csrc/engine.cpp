@@ -761,14 +761,13 @@ static int run_gemm(mellow_engine* e, const GemmArgs& a) {
         (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
         auto it = e->bf_w.find(a.Wp);
         if (it != e->bf_w.end()) {
-            CHK(ensure(e, e->a8, ((size_t)a.M * a.K * 6 + 3) / 4));
+            // fused kernel: A stays fp32 (global and LDS) and is split into its three bf16 terms in registers; the
+            // pre-split kernel (launch_split_rows + launch_gemm_bf16x3) remains reachable through mellow_debug_gemm_f32
             GemmArgs g = a;
-            g.A8 = reinterpret_cast<const uint8_t*>(e->a8.p); g.lda8 = (int64_t)3 * (a.K >> 3);
             g.W8 = reinterpret_cast<const uint8_t*>(it->second);
             ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
             ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 200;
-            launch_split_rows(a.A, a.lda, a.M, a.K, e->a8.p, e->stream);
-            launch_gemm_bf16x3(g, e->f32x3_terms, e->stream);
+            launch_gemm_bf16x3_fused(g, e->stream);
             return 0;
         }
     }
@@ -1457,7 +1456,7 @@ int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, flo
 int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C_out,
                           int iters, float* ms2) {
     if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return fail("bad argument");
-    if (mode != 0 && mode != 6 && mode != 9) return fail("mode must be 0, 6 or 9");
+    if (mode != 0 && mode != 6 && mode != 9 && mode != 16) return fail("mode must be 0, 6, 9 or 16 (fused 6-term)");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int NP = rup(N, 128);
@@ -1478,6 +1477,7 @@ int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, i
     g.A8 = reinterpret_cast<const uint8_t*>(dA3); g.lda8 = (int64_t)3 * (K >> 3); g.W8 = reinterpret_cast<const uint8_t*>(dPB);
     auto run = [&](bool pre, bool main) {
         if (mode == 0) { if (main) launch_gemm(g, s); }
+        else if (mode == 16) { if (main) launch_gemm_bf16x3_fused(g, s); }
         else { if (pre) launch_split_rows(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3(g, mode, s); }
     };
     run(true, true);

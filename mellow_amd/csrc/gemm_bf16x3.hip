@@ -11,6 +11,8 @@
 //   pack_bf16x3  W fp32 P-layout -> PB [n/32][k/16][3][lane][8 bf16]               (once per tensor at load time)
 //   gemm         128 x 128 tile, 4 waves, one k16 step per stage (12 KiB per operand), double-buffered LDS in
 //                fragment order, 12 ds_read_b128 feed 4 x TERMS MFMAs; shared epilogues (gemm_epilogue.h).
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -180,6 +182,115 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmBDev p) {
     }
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
+
+// ---- fused variant: A stays fp32 in global memory and in LDS and is split in registers after the fragment read -----------
+// No pre-pass, A traffic identical to the fp32 kernel; only the (pre-split, PB-layout) weight costs 6 bytes per element.
+// stage = one k32: A [k16 2][float4 half 2][m-tile 4][64 lanes] x 16 B = 16 KiB (lane-linear b128 fragment reads),
+//                  W [k16 2][piece 3][n-tile 4][64] x 16 B = 24 KiB; two stages = 80 KiB (dynamic LDS), 2 workgroups per CU.
+template <int EPI, int KS16>
+__global__ __launch_bounds__(256) void gemm_bf16x3f_kernel(const GemmBDev p) {
+    constexpr int BM = 128, BN = 128, WN = 2;
+    constexpr int A_STAGE = KS16 * 2 * 4 * 64, W_STAGE = KS16 * 3 * 4 * 64;     // 16-byte slots
+    constexpr int NA = KS16 * 2, NW = KS16 * 3;                             // float4 / 16-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) i32x4 smem_bf[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem_bf);                          // [2][A_STAGE]
+    i32x4* Ws = smem_bf + 2 * A_STAGE;                                      // [2][W_STAGE]
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
+    const int pm = L / p.gn, pn = L % p.gn;
+    const int K16 = g.K >> 4, KT = K16 / KS16;
+    const bool wave_active = (pn * BN + wn * 64) < g.Nw;
+    const i32x4* PB = reinterpret_cast<const i32x4*>(g.W8);
+
+    const float* a_ptr[NA];
+    int a_lds[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int idx = q * 256 + tid;
+        constexpr int CHK = 4 * KS16;                    // float4 chunks per row per stage
+        const int row = (idx / (8 * CHK)) * 8 + (idx & 7);   // 8 consecutive lanes -> 8 rows, next lane bits -> the chunks of a row
+        const int chunk = (idx >> 3) % CHK;              // k = 4 chunk .. 4 chunk + 3 of the stage
+        int m = pm * BM + row;
+        m = m < g.M ? m : g.M - 1;
+        a_ptr[q] = g.A + (int64_t)m * g.lda + chunk * 4;
+        const int s16 = chunk >> 2, kh = (chunk >> 1) & 1, half4 = chunk & 1;
+        a_lds[q] = ((s16 * 2 + half4) * 4 + (row >> 5)) * 64 + (row & 31) + 32 * kh;
+    }
+    const i32x4* w_ptr[NW];
+    int w_lds[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const int c = q * 256 + tid;
+        const int ntl = c / (192 * KS16), rem = c % (192 * KS16), s16 = rem / 192, r2 = rem % 192;
+        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * K16 + s16) * 192 + r2;
+        w_lds[q] = s16 * (3 * 4 * 64) + ((r2 >> 6) * 4 + ntl) * 64 + (r2 & 63);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA];
+    i32x4 rw[NW];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) ra[q] = *reinterpret_cast<const f32x4*>(a_ptr[q]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) rw[q] = w_ptr[q][0];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) As[a_lds[q]] = ra[q];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) Ws[w_lds[q]] = rw[q];
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = kt + 1 < KT ? kt + 1 : kt;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) ra[q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + ktn * 16 * KS16);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) rw[q] = w_ptr[q][(int64_t)ktn * KS16 * 192];
+        if (wave_active) {
+            const f32x4* Ac = As + cur * A_STAGE + (2 * wm) * 64 + lane;
+            const i32x4* Wc = Ws + cur * W_STAGE + (2 * wn) * 64 + lane;
+#pragma unroll
+            for (int s16 = 0; s16 < KS16; ++s16) {
+                i32x4 a[2][3], w[2][3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 lo = Ac[((s16 * 2 + 0) * 4 + t) * 64], hi = Ac[((s16 * 2 + 1) * 4 + t) * 64];
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    split8(v, a[t][0], a[t][1], a[t][2]);
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) w[t][pc] = Wc[s16 * (3 * 4 * 64) + (pc * 4 + t) * 64];
+                }
+                // term-major: consecutive MFMAs go to four different accumulators (no back-to-back dependence);
+                // per accumulator the order is still smallest partial product first
+#define MELLOW_TERM(PW, PA)                                   \
+                MELLOW_BF(w[0][PW], a[0][PA], acc[0][0])      \
+                MELLOW_BF(w[0][PW], a[1][PA], acc[0][1])      \
+                MELLOW_BF(w[1][PW], a[0][PA], acc[1][0])      \
+                MELLOW_BF(w[1][PW], a[1][PA], acc[1][1])
+                MELLOW_TERM(2, 0)
+                MELLOW_TERM(0, 2)
+                MELLOW_TERM(1, 1)
+                MELLOW_TERM(1, 0)
+                MELLOW_TERM(0, 1)
+                MELLOW_TERM(0, 0)
+#undef MELLOW_TERM
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) As[(cur ^ 1) * A_STAGE + a_lds[q]] = ra[q];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) Ws[(cur ^ 1) * W_STAGE + w_lds[q]] = rw[q];
+        __syncthreads();
+    }
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
+}
 #undef MELLOW_BF
 
 template <int EPI>
@@ -190,6 +301,35 @@ static void launchb(const GemmArgs& a, int terms, hipStream_t s) {
     d.gn = (a.Nw + 127) / 128;
     if (terms == 6) hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 6>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 9>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
+}
+template <int EPI>
+static void launchbf(const GemmArgs& a, hipStream_t s) {
+    GemmBDev d;
+    d.a = a;
+    d.gm = (a.M + 127) / 128;
+    d.gn = (a.Nw + 127) / 128;
+    static const int ks16 = getenv("MELLOW_F32X3_KS16") ? atoi(getenv("MELLOW_F32X3_KS16")) : 1;   // k16 steps per LDS stage
+    if (ks16 == 2 && a.K % 32 == 0) {
+        const size_t lds = (size_t)2 * (2 * 2 * 4 * 64 + 2 * 3 * 4 * 64) * 16;     // 80 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3f_kernel<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 2>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    } else {
+        const size_t lds = (size_t)2 * (2 * 4 * 64 + 3 * 4 * 64) * 16;             // 40 KiB
+        hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 1>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    }
+}
+// fused variant: g.A (fp32, row-major, lda) + g.W8 (PB); K % 32 == 0; six partial products
+void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_LINEAR: launchbf<EPI_LINEAR>(a, s); break;
+        case EPI_SWIGLU: launchbf<EPI_SWIGLU>(a, s); break;
+        case EPI_QKV_ROPE: launchbf<EPI_QKV_ROPE>(a, s); break;
+        default: break;
+    }
 }
 void launch_gemm_bf16x3(const GemmArgs& a, int terms, hipStream_t s) {
     switch (a.epi) {

@@ -78,6 +78,7 @@ void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, 
 void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s);
 void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s);
 void launch_gemm_bf16x3(const GemmArgs& a, int terms /* 6 or 9 partial products */, hipStream_t s);   // K % 16 == 0
+void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s);   // A split in registers (no pre-pass), K % 32 == 0, a_mode == A_PLAIN
 double gemm_flops(const GemmArgs& a);
 
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------

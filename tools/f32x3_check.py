@@ -19,7 +19,7 @@ for M, N, K in ((389, 576, 576), (1000, 960, 1536), (12448, 3072, 576), (12448, 
     scale = exact.abs().max().item()
     cpu = (A @ W.T).double()
     line = f"M {M} N {N} K {K}: torch-CPU fp32 max err {(cpu - exact).abs().max().item() / scale:.2e} |"
-    for mode, name in ((0, "fp32 MFMA"), (9, "bf16x3 9-term"), (6, "bf16x3 6-term")):
+    for mode, name in ((0, "fp32 MFMA"), (6, "bf16x3 6-term"), (16, "bf16x3 fused")):
         Cc, ms = eng.debug_gemm_f32(A, W, mode=mode, iters=10)
         err = (Cc.double() - exact).abs()
         tf = 2.0 * M * N * K / ms[1] / 1e9
