@@ -70,6 +70,30 @@ def cpu_baseline(max_len: int, threads: int):
     }
 
 
+def alt_modes(B: int, L: int):
+    """Supplementary, never the headline: the two opt-in numeric modes on the same workload (3 passes each)."""
+    from mellow_amd import synth
+    from mellow_amd.engine import Engine
+    sd = synth.make_state_dict(0)
+    a1, a2, ids = synth.make_batch(B)
+    res = {}
+    for prec, note in (("f32x3", "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)"),
+                       ("fp8", "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill; not bit-exact (DESIGN 6b)")):
+        e = Engine(device=0, max_positions=1024, precision=prec)
+        e.load_state_dict(sd)
+        a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
+        e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            _, _, _, ftm = e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+        torch.cuda.synchronize()
+        res[prec] = {"value": round(3 * B / (time.perf_counter() - t0), 2), "unit": "responses/s",
+                     "first_token_ms": round(ftm, 2), "note": note}
+        e.close()
+    return res
+
+
 def pipelined(n_ctx: int, B: int, L: int, n_batches: int):
     """Supplementary: n_ctx engine contexts on one GPU, n_batches batches of B dealt round-robin (mellow_amd/serve.py)."""
     from mellow_amd import synth
@@ -103,6 +127,7 @@ def main():
     ap.add_argument("--precision", choices=("f32", "fp8", "f32x3"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) or fp8 (BASELINE config 5: e4m3 GEMMs in the encoder's "
                          "Swin linears and LM prefill; a different metric line, not comparable with the headline)")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the supplementary fp8 / f32x3 measurements")
     ap.add_argument("--inflight", type=int, default=0,
                     help="also measure N engine contexts pipelining the same batches on this GPU (supplementary "
                          "'pipelined' object; never the headline value)")
@@ -247,6 +272,8 @@ def main():
             out["reference_semantics"] = ref_sem
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if n_gpus == 1 and args.precision == "f32" and not args.no_alt_modes:
+            out["alt_modes"] = alt_modes(B, L)
         if n_gpus == 1 and args.inflight > 1:
             out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
         if n_gpus == 1 and not args.no_cpu_baseline:
