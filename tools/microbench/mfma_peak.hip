@@ -54,6 +54,24 @@ __global__ __launch_bounds__(256) void mfma_fp8_kernel(float* out, int iters, lo
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 123.456f) out[0] = s;
 }
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_bf16_kernel(float* out, int iters, int a0, int b0) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const bf16x8 a = __builtin_bit_cast(bf16x8, i32x4{a0, a0, a0, a0}), b = __builtin_bit_cast(bf16x8, i32x4{b0, b0, b0, b0});
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;
+}
 __global__ __launch_bounds__(256) void mfma_f8f6f4_kernel(float* out, int iters, int a0, int b0) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
@@ -111,6 +129,11 @@ int main() {
             const double ms = time_ms([&] { hipLaunchKernelGGL(mfma_fp8_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0x3838383838383838L, 0x3838383838383838L); });
             const double fl = (double)blocks * 4 * iters * 16 * 4 * (32.0 * 32 * 16 * 2);
             printf("32x32x16 fp8 (e4m3), 4 acc, %d waves/SIMD: %8.3f ms  %7.1f TFLOP/s\n", wps, ms, fl / ms / 1e9);
+        }
+        {
+            const double ms = time_ms([&] { hipLaunchKernelGGL(mfma_bf16_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0x3f803f80, 0x3f803f80); });
+            const double fl = (double)blocks * 4 * iters * 16 * 4 * (32.0 * 32 * 16 * 2);
+            printf("32x32x16 bf16, 4 acc, %d waves/SIMD: %8.3f ms  %7.1f TFLOP/s\n", wps, ms, fl / ms / 1e9);
         }
         {
             const double ms = time_ms([&] { hipLaunchKernelGGL(mfma_f8f6f4_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0x38383838, 0x38383838); });
