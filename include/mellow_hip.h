@@ -131,8 +131,9 @@ int  mellow_debug_tap(mellow_engine_t* e, const char* name, float* out, int64_t 
 
 /* Numeric taps on HOST data (work on any engine, finalised or not): C[M][N] = A[M][K] . W[N][K]^T through one GEMM kernel.
  * iters > 0 and ms2 != NULL: ms2[0] / ms2[1] receive the average milliseconds of the operand pre-pass / of the GEMM.
- *   mellow_debug_gemm_f32: mode 0 = the exact fp32 MFMA kernel (no pre-pass), 9 / 6 = the bf16x3 split kernel with all nine /
- *     the six largest partial products (MELLOW_PRECISION_F32X3).  K % 32 == 0, N % 4 == 0.
+ *   mellow_debug_gemm_f32: mode 0 = the exact fp32 MFMA kernel (no pre-pass), 9 / 6 = the bf16x3 kernel on pre-split rows with
+ *     all nine / the six largest partial products, 16 = the fused six-product kernel MELLOW_PRECISION_F32X3 runs (A split in
+ *     registers, no pre-pass).  K % 32 == 0, N % 4 == 0.
  *   mellow_debug_gemm_fp8: the MELLOW_PRECISION_FP8 GEMM -- A quantised per row and W per row to OCP e4m3 (scale =
  *     amax / 448, round to nearest even), exact products, fp32 accumulation.  K % 64 == 0, N % 4 == 0. */
 int  mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C,

@@ -278,7 +278,8 @@ class Engine:
         return out
 
     def debug_gemm_f32(self, A: torch.Tensor, W: torch.Tensor, mode: int = 0, iters: int = 0):
-        """C = A . W^T through the exact fp32 MFMA kernel (mode 0) or the bf16x3 split kernel (mode 9 / 6); host tensors."""
+        """C = A . W^T through the exact fp32 MFMA kernel (mode 0) or a bf16x3 split kernel (9 / 6: pre-split rows; 16: the fused
+        kernel the f32x3 mode runs); host tensors."""
         A = A.detach().cpu().contiguous().float()
         W = W.detach().cpu().contiguous().float()
         (M, K), (N, K2) = A.shape, W.shape
