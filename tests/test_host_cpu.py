@@ -146,3 +146,14 @@ def test_dp_gather_two_process_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_cli_contract_flags():
+    """bench.py must accept the driver's flags (and the supplementary ones) without touching a GPU: --help exits 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--inflight", "--no-cpu-baseline"):
+        assert flag in r.stdout
