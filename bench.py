@@ -35,39 +35,102 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 matrix peak (same guide); the 32x32x16 fp8 form used here sustains 2460
 PEAK_HBM_GBS = 8000.0
+PEAK_F32X3_TFLOPS = 2500.0 / 6.0   # f32x3 mode: six bf16 MFMA products per fp32 product on the 2.5 PF dense bf16 pipe
+PMC_TRAFFIC_FILE = "r02_pmc_gemm_traffic.json"
+FFT_GFLOP_PER_CLIP = 0.051         # algorithmic cost of the STFT; the kernel runs it as a dense DFT GEMM (2.10 GF/clip)
 
 # algorithmic work per response at max_len = 64, prefix 389
 DENSE_GFLOP_PER_RESPONSE = 24.33 + 87.90          # encoder (2 clips) + LM prefill -> MFMA-bound part
-DECODE_GB_PER_RESPONSE_B32 = 2.28                 # fp32 weights/B + KV pages, B = 32 -> HBM-bound part
 
 
-def cpu_baseline(max_len: int, threads: int):
-    """The oracle (CPU port of the reference algorithm, no KV cache) on a bounded sample: one example,
-    encoder + prefix once, then 24 full re-forward decode steps; the remaining steps are extrapolated
-    linearly in sequence length (the reference's per-step cost is ~ proportional to 389+i)."""
+def kernel_source_sha16() -> str:
+    """sha256 over the kernel + engine sources: committed PMC results carry it, so a stale file is never printed."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mellow_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def decode_algorithmic_bytes(B: int, L: int, T0: int = 389) -> float:
+    """SURVEY.md 8(d), fp32 exact mode: per decode step the 538.06 MB of weights once, plus per example 46,080 B for every
+    cached token read and for the one appended; steps 1..L-1 (token 0 comes from the prefill)."""
+    w = 134_515_008 * 4.0
+    return sum(w + B * 46080.0 * (T0 + i + 1) for i in range(1, L))
+
+
+def cpu_baseline(max_len: int):
+    """The oracle (CPU port of the reference algorithm, no KV cache) on a bounded sample, on ALL host cores:
+    the thread count is chosen by timing a short run with min(32, cores) and with every core; B = 1 (encoder + prefix once,
+    then 24 full re-forward decode steps) and B = 4 (12 steps); the remaining steps are extrapolated linearly in sequence
+    length (the reference's per-step cost is proportional to 389+i)."""
     from mellow_amd import synth
     from oracle import mellow_oracle as O
-    torch.set_num_threads(threads)
+    cores = os.cpu_count() or 1
     sd = synth.make_state_dict(0)
-    a1, a2, ids = synth.make_batch(1)
     lm = O.LMParams()
-    with torch.no_grad():
+    a1, a2, ids = synth.make_batch(4)
+
+    def run(B, n_meas):
+        with torch.no_grad():
+            t0 = time.time()
+            prefix = O.generate_prefix_inference(sd, torch.from_numpy(a1[:B]), torch.from_numpy(a2[:B]), torch.from_numpy(ids[:B]))
+            t_enc = time.time() - t0
+            t0 = time.time()
+            O.generate_batch(sd, lm, prefix, n_meas, 0.8, 1.0, -1, last_only=False)
+            t_steps = time.time() - t0
+        T0 = prefix.shape[1]
+        per = t_steps / sum(T0 + i for i in range(n_meas))              # seconds per (step x sequence position) of the batch
+        total = t_enc + per * sum(T0 + i for i in range(max_len))
+        return {"responses_per_s": round(B / total, 5), "first_token_s": round(t_enc + per * T0, 3),
+                "encode_s": round(t_enc, 3), "steps_measured": n_meas, "steps_s": round(t_steps, 3)}
+
+    tried = {}
+    for th in sorted({min(32, cores), cores}):
+        torch.set_num_threads(th)
         t0 = time.time()
-        prefix = O.generate_prefix_inference(sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids))
-        t_enc = time.time() - t0
-        n_meas = 24
-        t0 = time.time()
-        O.generate_batch(sd, lm, prefix, n_meas, 0.8, 1.0, -1, last_only=False)
-        t_steps = time.time() - t0
-    T0 = prefix.shape[1]
-    per_tok_step = t_steps / sum(T0 + i for i in range(n_meas))            # seconds per (step x sequence position)
-    t_total = t_enc + per_tok_step * sum(T0 + i for i in range(max_len))
+        run(1, 3)
+        tried[th] = round(time.time() - t0, 3)
+    threads = min(tried, key=tried.get)
+    torch.set_num_threads(threads)
+    b1 = run(1, 24)
+    b4 = run(4, 12)
+    best = max(b1["responses_per_s"], b4["responses_per_s"])
     return {
-        "value": round(1.0 / t_total, 5), "unit": "responses/s", "cores": threads, "kind": "port",
-        "sample": f"B=1: front-end+encoder+prefix ({t_enc:.2f}s) + {n_meas} no-KV-cache decode steps ({t_steps:.2f}s), "
-                  f"extrapolated linearly in sequence length to max_len={max_len}",
-        "first_token_s": round(t_enc + per_tok_step * T0, 3),
+        "value": best, "unit": "responses/s", "cores": threads, "cores_available": cores, "threads_used": threads,
+        "threads_tried_s": {str(k): v for k, v in tried.items()}, "kind": "port",
+        "sample": f"oracle (no KV cache, fp32) on {threads} of {cores} host threads (faster of the counts tried on a 3-step run): "
+                  f"B=1 encoder+prefix + 24 decode steps, B=4 encoder+prefix + 12 decode steps, each extrapolated linearly in "
+                  f"sequence length to max_len={max_len}; value = the better of the two batch sizes",
+        "b1": b1, "b4": b4, "first_token_s": b1["first_token_s"],
     }
+
+
+def north_star_b64(L: int):
+    """The north_star's stated batch (64 examples per GPU, 2x10 s clips, max_len 64) on this GPU: 2 timed passes."""
+    from mellow_amd import synth
+    from mellow_amd.engine import Engine
+    e = Engine(device=0)
+    e.load_state_dict(synth.make_state_dict(0))
+    a1, a2, ids = synth.make_batch(64)
+    a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
+    e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        _, _, _, ftm = e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    ph = e.last_phase_ms()
+    e.close()
+    t_roof = 64 * (DENSE_GFLOP_PER_RESPONSE / (PEAK_F32_MFMA_TFLOPS * 1e3)) + decode_algorithmic_bytes(64, L) / (PEAK_HBM_GBS * 1e9)
+    return {"batch": 64, "value": round(64 / dt, 2), "unit": "responses/s", "ms_per_pass": round(dt * 1e3, 2),
+            "first_token_ms": round(ftm, 2), "phase_ms": {k: round(v, 2) for k, v in ph.items()},
+            "decode_ms_per_step": round(ph["decode_ms"] / (L - 1), 4),
+            "path_roofline_frac": round(t_roof * 1e3 / (dt * 1e3), 4)}
 
 
 def alt_modes(B: int, L: int):
@@ -79,7 +142,7 @@ def alt_modes(B: int, L: int):
     res = {}
     for prec, note in (("f32x3", "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)"),
                        ("fp8", "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill; not bit-exact (DESIGN 6b)")):
-        e = Engine(device=0, max_positions=1024, precision=prec)
+        e = Engine(device=0, precision=prec)
         e.load_state_dict(sd)
         a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
         e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
@@ -128,6 +191,7 @@ def main():
                     help="f32 (default, the headline: exact fp32 MFMA) or fp8 (BASELINE config 5: e4m3 GEMMs in the encoder's "
                          "Swin linears and LM prefill; a different metric line, not comparable with the headline)")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the supplementary fp8 / f32x3 measurements")
+    ap.add_argument("--no-b64", action="store_true", help="skip the supplementary batch-64 (north_star) measurement")
     ap.add_argument("--inflight", type=int, default=0,
                     help="also measure N engine contexts pipelining the same batches on this GPU (supplementary "
                          "'pipelined' object; never the headline value)")
@@ -156,7 +220,7 @@ def main():
     from mellow_amd import synth, dist as mdist
     from mellow_amd.engine import Engine
     dev = local_rank if world > 1 else 0
-    eng = Engine(device=dev, max_positions=1024, precision=args.precision)     # raises if libmellow_hip.so or the GPU is missing
+    eng = Engine(device=dev, precision=args.precision)     # raises if libmellow_hip.so or the GPU is missing
     eng.load_state_dict(synth.make_state_dict(0))
     comm_dev = eng.tdev if backend == "nccl" else torch.device("cpu")      # where the collectives' buffers live
     B, L = args.batch, args.max_len
@@ -200,7 +264,7 @@ def main():
             _, _, steps_run, _ = eng.generate(a1d, a2d, idsd, max_len=L, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=False)
         torch.cuda.synchronize()
         ref_sem = {"value": round(n_ref * B / (time.perf_counter() - t1), 2), "unit": "responses/s", "passes": n_ref,
-                   "steps_run": int(steps_run), "note": "stop id honoured (reference loop exit rule); synthetic weights never emit it"}
+                   "steps_run": int(steps_run), "steps_enqueued": eng.last_steps_enqueued(), "note": "stop id honoured (reference loop exit rule); synthetic weights never emit it"}
 
     # ---- PCIe-inclusive rate: the same pass with the waveforms and prompt ids starting in (pageable) host memory ----
     pcie = None
@@ -208,11 +272,15 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n_p = max(1, min(3, args.steps))
+        ft_host = []
         for _ in range(n_p):
-            eng.generate(eng._f32(a1), eng._f32(a2), eng._i32(ids), max_len=L, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
+            eng.generate(a1, a2, ids, max_len=L, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
+            ft_host.append(eng.last_first_token_host_ms)
         torch.cuda.synchronize()
         pcie = {"value": round(n_p * B / (time.perf_counter() - t1), 2), "unit": "responses/s", "passes": n_p,
-                "note": f"host->device copy of 2 x {B} x 1.28 MB waveforms + ids inside the timed region (never the headline)"}
+                "first_token_ms_p50": round(statistics.median(ft_host), 2),
+                "note": f"inputs start in pageable HOST memory: host->device copy of 2 x {B} x 1.28 MB waveforms + ids inside the "
+                        f"timed region (never the headline); first_token_ms_p50 here is SURVEY 8d's latency definition"}
 
     # ---- roofline of the dominant kernel family, HIP events on the engine's stream over one more step ----
     eng.prof_enable(True)
@@ -224,22 +292,34 @@ def main():
     if rank == 0:
         # HBM-side traffic of the dominant kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
         # in separate runs, gfx950 x2 read correction applied): it cannot be sampled from inside this process
-        traffic = None
+        traffic, traffic_note = None, "no PMC result committed for the current kernel sources"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
-                traffic = round(json.load(f)["traffic_bytes_per_launch"])
+            with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+                pj = json.load(f)
+            if pj.get("source_sha16") == kernel_source_sha16():
+                traffic = round(pj["traffic_bytes_per_launch"])
+                traffic_note = f"bytes per launch (memory-side, PMC, profiles/{PMC_TRAFFIC_FILE}, same kernel sources)"
+            else:
+                traffic_note = (f"profiles/{PMC_TRAFFIC_FILE} was measured on other kernel sources (sha {pj.get('source_sha16')} "
+                                f"!= {kernel_source_sha16()}): not printed; regenerate with tools/pmc_prefill.py + tools/pmc_traffic.py")
         except Exception:
             pass
         total = n_gpus * B * args.steps
         value = total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         g = rep["gemm_f32_mfma"]
-        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # ALGORITHMIC flops: the STFT is priced as the FFT it could be (0.051 GF/clip), not as the dense DFT
+        # GEMM the kernel runs (2 x frames x 1024 x 1026 flops per clip); the dense figure is kept beside it
+        dense_dft = 2.0 * (2 * B) * 1001 * 1024 * 1026
+        flops_alg = g["flops"] - dense_dft + (2 * B) * FFT_GFLOP_PER_CLIP * 1e9
+        tf = flops_alg / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        tf_dense = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        dec_bytes = decode_algorithmic_bytes(B, L)
+        dec_gbs = dec_bytes / (phases["decode_ms"] * 1e-3) / 1e9 if phases["decode_ms"] > 0 else 0.0
         # whole-path two-phase roofline: t_roof = F_dense/P_mfma + Bytes_decode/BW_hbm
-        t_roof = (DENSE_GFLOP_PER_RESPONSE / ((PEAK_FP8_MFMA_TFLOPS if args.precision == "fp8" else PEAK_F32_MFMA_TFLOPS) * 1e3)
-                  + DECODE_GB_PER_RESPONSE_B32 / PEAK_HBM_GBS) * B
         fp8 = args.precision == "fp8"
-        peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32X3_TFLOPS if args.precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+        t_roof = DENSE_GFLOP_PER_RESPONSE / (peak * 1e3) * B + dec_bytes / (PEAK_HBM_GBS * 1e9)
         out = {
             "metric": "audio-pair responses/sec (v0 167M, 2x10s clips, max_len=64, greedy)" +
                       (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else "") +
@@ -259,10 +339,21 @@ def main():
             "roofline": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
                                     if fp8 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),
                          "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(tf / peak, 4), "traffic": None if fp8 else traffic,
-                         "traffic_unit": "bytes per launch (memory-side, PMC, profiles/r01_pmc_gemm_traffic.json)",
+                         "frac": round(tf / peak, 4), "traffic": None if args.precision != "f32" else traffic,
+                         "traffic_unit": traffic_note,
                          "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
-                         "flops_per_step": g["flops"]},
+                         "flops_per_step": flops_alg,
+                         "achieved_dense_dft": round(tf_dense, 2),
+                         "note": "achieved = algorithmic flops (STFT priced as an FFT, SURVEY 8d) / family time measured live with "
+                                 "HIP events on the engine's stream; achieved_dense_dft counts the DFT GEMM's own flops"},
+            "roofline_decode": {"kernels": "dec_qkv | dec_attn | dec_oproj | dec_gateup16 | dec_down x 30 + final norm, lm_head, arg-max "
+                                           "per step (hipGraph replay)",
+                                "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(dec_gbs / PEAK_HBM_GBS, 4), "steps": L - 1,
+                                "ms_per_step": round(phases["decode_ms"] / max(1, L - 1), 4),
+                                "bytes_per_step_avg": round(dec_bytes / max(1, L - 1)),
+                                "note": "algorithmic bytes (538.06 MB fp32 weights + 46,080 B per cached token per example, SURVEY 8d) "
+                                        "/ decode phase time (HIP events, timed pass)"},
             "path_roofline": {"t_roof_ms_per_step": round(t_roof * 1e3, 3),
                               "frac": round(t_roof * 1e3 / ms_per_step, 4),
                               "definition": "F_dense/P_mfma(dtype) + Bytes_decode/8TB/s per response x batch (SURVEY 8d)"},
@@ -276,8 +367,10 @@ def main():
             out["alt_modes"] = alt_modes(B, L)
         if n_gpus == 1 and args.inflight > 1:
             out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
+        if n_gpus == 1 and args.precision == "f32" and not args.no_b64 and B != 64:
+            out["north_star_b64"] = north_star_b64(L)
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, threads=min(32, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(L)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

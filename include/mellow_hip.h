@@ -90,7 +90,11 @@ const char* mellow_engine_required_key(int i);
  * out_tokens    : dev i32 [B][max_len]; columns >= *out_steps are undefined
  * out_len       : host i32 [B], tokens before the row's first stop_id (the text cut of wrapper.py:254)
  * out_steps     : host, number of loop iterations the reference would have run
- * first_token_ms: host, time from call entry until the first token id of every row is on the device
+ * first_token_ms: host wall-clock milliseconds from call entry until the first token id of every row exists
+ *                 (observed through the device's progress word, without synchronising the stream)
+ * In reference-semantics mode the host follows the stop rule one step behind the device through a mapped progress
+ * word the arg-max kernel publishes: no stream synchronisation inside the loop, at most one step is enqueued past
+ * the deciding one (mellow_last_steps_enqueued reports how many were).
  */
 int  mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
                      const int32_t* input_ids, int B, int max_len, float top_p, float temperature,
@@ -156,6 +160,8 @@ int         mellow_prof_get(mellow_engine_t* e, int i, int64_t* launches, double
 /* phase wall times of the last mellow_generate call (HIP events): front-end+encoder+prefix, prefill,
  * decode loop; milliseconds */
 int         mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms, float* decode_ms);
+/* decode steps (counting the prefill's token) the last mellow_generate call enqueued: *out_steps, or *out_steps + 1 */
+int         mellow_last_steps_enqueued(mellow_engine_t* e);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

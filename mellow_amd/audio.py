@@ -18,8 +18,26 @@ import torch
 import torch.nn.functional as F
 
 
-def load_wav(path: str) -> Tuple[torch.Tensor, int]:
-    """-> (float32 tensor (channels, n) in [-1, 1), sample_rate), like torchaudio.load(normalize=True)."""
+def _decode_file(path: str) -> Tuple[np.ndarray, int]:
+    """-> (float32 (channels, n), sample_rate).  Decoders are tried in the order torchaudio (what the reference uses,
+    wrapper.py:144) -> soundfile -> scipy.io.wavfile -> stdlib wave; the first two are optional dependencies."""
+    errors = []
+    try:
+        import torchaudio  # optional: not a dependency of this package
+        wav, sr = torchaudio.load(path)
+        return wav.numpy().astype(np.float32, copy=False), int(sr)
+    except ImportError:
+        pass
+    except Exception as e:  # pragma: no cover - depends on the installed backend
+        errors.append(f"torchaudio: {e}")
+    try:
+        import soundfile  # optional: FLAC / OGG / WAV-extensible
+        data, sr = soundfile.read(path, dtype="float32", always_2d=True)
+        return np.ascontiguousarray(data.T), int(sr)
+    except ImportError:
+        pass
+    except Exception as e:  # pragma: no cover
+        errors.append(f"soundfile: {e}")
     try:
         from scipy.io import wavfile
         sr, data = wavfile.read(path)
@@ -33,14 +51,34 @@ def load_wav(path: str) -> Tuple[torch.Tensor, int]:
             x = (data.astype(np.float32) - 128.0) / 128.0
         else:
             x = data.astype(np.float32)
-        return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
-    except ImportError:  # pragma: no cover - scipy is present in the image; stdlib fallback for s16 PCM
+        return np.ascontiguousarray(x.T), int(sr)
+    except ImportError:  # pragma: no cover - scipy is present in the image
+        pass
+    except Exception as e:
+        errors.append(f"scipy.io.wavfile: {e}")
+    try:
         with wave.open(path, "rb") as w:
             sr, ch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
             if sw != 2:
-                raise ValueError(f"{path}: only 16-bit PCM supported without scipy")
+                raise ValueError("only 16-bit PCM is supported by the stdlib decoder")
             data = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch)
-        return torch.from_numpy((data.astype(np.float32) / 32768.0).T.copy()), sr
+        return (data.astype(np.float32) / 32768.0).T.copy(), sr
+    except Exception as e:
+        errors.append(f"wave: {e}")
+    raise ValueError(f"{path}: cannot decode audio.  Without torchaudio or soundfile installed only PCM / float WAV files "
+                     f"are supported (FLAC, MP3, OGG need one of them).  Decoder errors: " + "; ".join(errors))
+
+
+def load_wav(path: str) -> Tuple[torch.Tensor, int]:
+    """-> (float32 tensor (channels, n) in [-1, 1), sample_rate), like torchaudio.load(normalize=True).
+    Non-finite samples (float WAVs can hold NaN / Inf) are replaced by 0 / +-1 with a warning: one NaN would poison every
+    logit of its example (the reference would emit garbage text for it; an engine must not fault on it)."""
+    x, sr = _decode_file(path)
+    if not np.isfinite(x).all():
+        import warnings
+        warnings.warn(f"{path}: non-finite samples replaced (NaN -> 0, +-Inf -> +-1)")
+        x = np.nan_to_num(x, nan=0.0, posinf=1.0, neginf=-1.0)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), int(sr)
 
 
 def _sinc_resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):

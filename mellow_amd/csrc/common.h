@@ -56,6 +56,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return half_max(v);
 }
 
+// torch.argmax order (reference wrapper.py:232): NaN compares as the maximum, and among equal values (or several NaNs)
+// the lowest index wins.  With (-inf, INT_MAX) as the start value the result is always a valid index.
+__device__ __forceinline__ bool arg_better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > bv || (v == bv && i < bi);
+}
+
 // exact-erf GELU (nn.GELU() default, reference htsat.py:121 / mellow.py:50)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
         int bi = n;
 #pragma unroll
         for (int j = 1; j < 4; ++j)
-            if (v[j] > bv) { bv = v[j]; bi = n + j; }
+            if (arg_better(v[j], n + j, bv, bi)) { bv = v[j]; bi = n + j; }
         red[tid] = bv;
         reinterpret_cast<int*>(red)[256 + tid] = bi;
         __syncthreads();
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
             for (int q = 1; q < 8; ++q) {
                 const float ov = red[tid + 32 * q];
                 const int oi = reinterpret_cast<int*>(red)[256 + tid + 32 * q];
-                if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+                if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
             }
             const int64_t o = ((int64_t)rb * 32 + tid) * gridDim.x + nt;
             a.cand_val[o] = best;
@@ -631,9 +631,7 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, co
 // record the token at column (*d_pos - T0 + 1), track stop ids, and gather its embedding row (embed_tokens,
 // wrapper.py:237) as the next step's residual stream (row-major + F32-layout).
 __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n, int32_t* __restrict__ tokens,
-                                                         const float* __restrict__ embed, int write_x,
-                                                         int32_t* __restrict__ out_tokens, int max_len, int T0,
-                                                         int stop_id, int32_t* seen_stop, int32_t* n_seen) {
+                                                         const float* __restrict__ embed, int write_x, const LoopArgs lp) {
     __shared__ float bv[4];
     __shared__ int bi[4];
     __shared__ int tok_s;
@@ -643,27 +641,39 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
     for (int i = tid; i < n; i += 256) {
         const float v = a.cand_val[(int64_t)b * n + i];
         const int id = a.cand_idx[(int64_t)b * n + i];
-        if (v > best || (v == best && id < idx)) { best = v; idx = id; }
+        if (arg_better(v, id, best, idx)) { best = v; idx = id; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(idx, off, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
     }
     if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+            if (arg_better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
+        idx = min(max(idx, 0), n * 32 - 1);       // always a valid row of the embedding table (n tiles x 32 ids = vocab)
         tokens[b] = idx;
         tok_s = idx;
-        if (out_tokens) {
-            const int step = *a.d_pos - T0 + 1;
-            if (step >= 0 && step < max_len) out_tokens[(int64_t)b * max_len + step] = idx;
-            if (idx == stop_id && seen_stop[b] == 0) {
-                seen_stop[b] = 1;
-                atomicAdd(n_seen, 1);
+        if (lp.out_tokens) {
+            const int max_len = lp.params[0], stop_id = lp.params[1];
+            const int step = *a.d_pos - lp.T0 + 1;
+            if (step >= 0 && step < max_len) lp.out_tokens[(int64_t)b * max_len + step] = idx;
+            if (idx == stop_id && lp.seen_stop[b] == 0) {
+                lp.seen_stop[b] = 1;
+                atomicAdd(lp.n_seen, 1);
+            }
+            // the last row of this launch publishes the step: ticket = arg-max launches so far, low word = rows stopped
+            __threadfence();
+            if (atomicAdd(lp.arrive, 1) == (int)gridDim.x - 1) {
+                *lp.arrive = 0;
+                const int t = *lp.ticket + 1;
+                *lp.ticket = t;
+                const int ns = atomicAdd(lp.n_seen, 0);
+                __hip_atomic_store(lp.host_progress, ((unsigned long long)(unsigned)t << 32) | (unsigned)ns, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -678,9 +688,11 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
 
 // rows -> residual stream (row-major + F32-layout): src row b = in[row_of(b)]
 __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, const float* __restrict__ in, int64_t ld,
-                                                            const int32_t* __restrict__ row_ids, int T_last) {
+                                                            const int32_t* __restrict__ row_ids, int T_last, int n_src) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t src = row_ids ? (int64_t)row_ids[b] : (int64_t)b * T_last + (T_last - 1);
+    // caller-supplied ids are clamped to the table (an out-of-range id must not become a wild read; the Python
+    // binding rejects it with an IndexError before it gets here)
+    const int64_t src = row_ids ? (int64_t)min(max(row_ids[b], 0), n_src - 1) : (int64_t)b * T_last + (T_last - 1);
     if (tid < 144) {
         const float4 e = reinterpret_cast<const float4*>(in + src * ld)[tid];
         reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
@@ -714,14 +726,12 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
     hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
 }
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
-                       int32_t* out_tokens, int max_len, int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(dec_argmax_kernel, dim3(B), dim3(256), 0, s, a, n_tiles, tokens, embed, write_x, out_tokens, max_len,
-                       T0, stop_id, seen_stop, n_seen);
+                       const LoopArgs& loop, hipStream_t s) {
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(B), dim3(256), 0, s, a, n_tiles, tokens, embed, write_x, loop);
 }
 void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(dec_load_rows_kernel, dim3(B), dim3(192), 0, s, a, in, ld, row_ids, T_last);
+                          int n_src, hipStream_t s) {
+    hipLaunchKernelGGL(dec_load_rows_kernel, dim3(B), dim3(192), 0, s, a, in, ld, row_ids, T_last, n_src);
 }
 
 // ---- full-row arg-max (mellow_argmax tap): torch.argmax tie rule, float4 loads --------------------------------
@@ -738,20 +748,20 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (vv[j] > best) { best = vv[j]; idx = 4 * i + j; }   // increasing index order: first max wins
+            if (arg_better(vv[j], 4 * i + j, best, idx)) { best = vv[j]; idx = 4 * i + j; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(idx, off, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
     }
     if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 16; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        tokens[b] = idx;
+            if (arg_better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
+        tokens[b] = min(max(idx, 0), V - 1);
     }
 }
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s) {

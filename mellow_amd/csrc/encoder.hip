@@ -422,7 +422,7 @@ __device__ __forceinline__ float audio_row_value(const float* __restrict__ p33, 
 __global__ __launch_bounds__(192) void prefix_assemble_kernel(const float* __restrict__ proj33,
                                                               const float* __restrict__ embed,
                                                               const int32_t* __restrict__ ids, int B, int text_len,
-                                                              int sep_id, float* __restrict__ prefix) {
+                                                              int sep_id, int vocab, float* __restrict__ prefix) {
     const int pos = blockIdx.x, b = blockIdx.y;
     const int P = 2 * 129 + 2 + text_len;
     float* dst = prefix + ((int64_t)b * P + pos) * 576;
@@ -432,14 +432,14 @@ __global__ __launch_bounds__(192) void prefix_assemble_kernel(const float* __res
         else if (pos == 129) v = embed[(int64_t)sep_id * 576 + c];
         else if (pos < 259) v = audio_row_value(proj33 + (int64_t)(B + b) * 33 * 576, pos - 130, c);
         else if (pos == 259) v = embed[(int64_t)sep_id * 576 + c];
-        else v = embed[(int64_t)ids[(int64_t)b * text_len + (pos - 260)] * 576 + c];
+        else v = embed[(int64_t)min(max(ids[(int64_t)b * text_len + (pos - 260)], 0), vocab - 1) * 576 + c];   // clamped: see engine.py
         dst[c] = v;
     }
 }
 void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
-                            int sep_id, float* prefix, hipStream_t s) {
+                            int sep_id, int vocab, float* prefix, hipStream_t s) {
     hipLaunchKernelGGL(prefix_assemble_kernel, dim3(260 + text_len, B), dim3(192), 0, s, proj33, embed, ids, B,
-                       text_len, sep_id, prefix);
+                       text_len, sep_id, vocab, prefix);
 }
 __global__ __launch_bounds__(192) void downsample33_kernel(const float* __restrict__ proj33, float* __restrict__ out) {
     const int r = blockIdx.x, clip = blockIdx.y;

@@ -147,6 +147,13 @@ struct mellow_engine {
     Buf dlogits, cand;
     DecArgs da;
     int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
+    int32_t *d_arrive = nullptr, *d_ticket = nullptr, *d_params = nullptr;   // loop bookkeeping words (LoopArgs)
+    unsigned long long* h_progress = nullptr;  // mapped host word the arg-max kernel publishes (ticket << 32 | rows stopped) to
+    unsigned long long* d_progress = nullptr;  // its device alias
+    std::map<std::pair<int, int>, float*> resample_banks;   // (orig, new) gcd-reduced -> device polyphase bank [klen][new]
+    int32_t h_params[2] = {0, 0};              // staging of d_params {max_len, stop id}
+    int last_steps_enqueued = 0;               // decode steps (incl. the prefill's token) the last generate call enqueued
+    Buf out_tok;                               // engine-owned token record [rows][max_len] (stable address: graph-safe)
     int kv_B = 0, kv_Tmax = 0;                // current page geometry
     int cur_B = 0, cur_pos = 0;               // host mirror of the decode state
     int32_t h_pos_word = 0;                   // staging for the device position word
@@ -169,8 +176,7 @@ struct mellow_engine {
     hipGraphExec_t step_exec = nullptr;
     hipGraphExec_t step_exec8 = nullptr;      // the same step captured 8 times in a row (the step is position-independent)
     int step_exec_B = -1, step_exec_Tmax = -1;
-    int32_t* graph_out_tokens = nullptr;
-    int graph_max_len = -1, graph_stop = -1;
+    const void* graph_out_tok = nullptr;      // the graphs bake buffer addresses in; max_len / stop id travel in d_params
 
     // profiling
     bool prof_on = false;
@@ -420,7 +426,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
                                   &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dec,
-                                  &e->dlogits, &e->cand};
+                                  &e->dlogits, &e->cand, &e->out_tok};
     for (auto* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : e->taps)
@@ -429,6 +435,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     for (int i = 0; i < 4; ++i)
         if (e->ev_phase[i]) hipEventDestroy(e->ev_phase[i]);
     if (e->d_tokens) hipFree(e->d_tokens);
+    if (e->h_progress) hipHostFree(e->h_progress);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -467,10 +474,15 @@ static const HostTensor* get(mellow_engine* e, const std::string& k) {
 static int expect_shape(const HostTensor* t, const std::string& k, std::initializer_list<int64_t> shp) {
     if (!t) return fail("missing key in state_dict: %s", k.c_str());
     if (t->dtype != MELLOW_F32) return fail("%s: expected float32", k.c_str());
-    if (t->shape.size() != shp.size()) return fail("%s: rank mismatch", k.c_str());
+    if (t->shape.size() != shp.size())
+        return fail("size mismatch for %s: rank %d in the checkpoint, %d expected", k.c_str(), (int)t->shape.size(), (int)shp.size());
     size_t i = 0;
-    for (auto d : shp)
-        if (t->shape[i++] != d) return fail("size mismatch for %s", k.c_str());
+    for (auto d : shp) {
+        if (t->shape[i] != d)
+            return fail("size mismatch for %s: dimension %d is %lld in the checkpoint, %lld expected", k.c_str(), (int)i,
+                        (long long)t->shape[i], (long long)d);
+        ++i;
+    }
     return 0;
 }
 static int up_vec(mellow_engine* e, const std::string& k, int64_t n, float** out, int64_t pad_to = 0) {
@@ -560,8 +572,8 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(make_packed(e, mt.data(), nullptr, kMel, kNfreq, &e->mel));
         const HostTensor *w = get(e, E + "bn0.weight"), *b = get(e, E + "bn0.bias"), *rm = get(e, E + "bn0.running_mean"),
                          *rv = get(e, E + "bn0.running_var");
-        for (auto* t : {w, b, rm, rv})
-            if (t->numel() != kMel) return fail("size mismatch for bn0");
+        for (const char* nm : {"bn0.weight", "bn0.bias", "bn0.running_mean", "bn0.running_var"})
+            CHK(expect_shape(get(e, E + nm), E + nm, {kMel}));
         std::vector<float> al(kMel), be(kMel);
         for (int i = 0; i < kMel; ++i) {
             // eval BatchNorm: y = x*alpha + beta with alpha = w/sqrt(var+eps), beta = b - mean*alpha (fp32)
@@ -749,7 +761,13 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     e->d_step = e->d_tokens + 1024;
     e->d_pos = e->d_tokens + 1025;
     e->d_nseen = e->d_tokens + 1026;
+    e->d_arrive = e->d_tokens + 1027;
+    e->d_ticket = e->d_tokens + 1028;
+    e->d_params = e->d_tokens + 1032;
     e->d_seen = e->d_tokens + 2048;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped));
+    *e->h_progress = 0;
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_progress), e->h_progress, 0));
     e->host.clear();
     e->finalized = true;
     return 0;
@@ -1018,13 +1036,17 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
     return 0;
 }
 
-// loop bookkeeping fused into the arg-max kernel (reference wrapper.py:232-249)
+// loop bookkeeping fused into the arg-max kernel (reference wrapper.py:232-249): only mellow_generate records
 struct RecordArgs {
-    int32_t* out_tokens = nullptr;
-    int max_len = 0;
-    int stop_id = 0;
     bool embed_next = false;
 };
+static LoopArgs loop_args(mellow_engine* e) {
+    LoopArgs lp;
+    lp.out_tokens = reinterpret_cast<int32_t*>(e->out_tok.p);
+    lp.params = e->d_params; lp.seen_stop = e->d_seen; lp.n_seen = e->d_nseen; lp.arrive = e->d_arrive; lp.ticket = e->d_ticket;
+    lp.host_progress = e->d_progress; lp.T0 = e->cfg.prefix_len;
+    return lp;
+}
 
 // final norm (+ pending down slabs) + lm_head with fused per-tile arg-max candidates -> dlogits, d_tokens
 static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArgs* rec) {
@@ -1034,8 +1056,8 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
     { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * e->cfg.vocab_size, 576.0 * e->cfg.vocab_size * 4);
       launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
     { ProfScope ps(e, PF_MISC, 0, 0);
-      launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? rec->out_tokens : nullptr,
-                        rec ? rec->max_len : 0, e->cfg.prefix_len, rec ? rec->stop_id : 0, e->d_seen, e->d_nseen, e->stream); }
+      launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? loop_args(e) : LoopArgs(),
+                        e->stream); }
     return 0;
 }
 
@@ -1086,7 +1108,7 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
     // x now holds the input of the last layer.  Position word = index of the LAST prefix token: the decode kernels
     // treat it as "the new token" (keys 0..T-2 from the pages, key T-1 recomputed and re-appended), and the first
     // kernel of every later decode step advances it; the arg-max records its token at column (*d_pos - prefix_len + 1) = 0.
-    { ProfScope ps(e, PF_MISC, 0, 0); launch_dec_load_rows(e->da, B, x, 576, nullptr, T, s); }
+    { ProfScope ps(e, PF_MISC, 0, 0); launch_dec_load_rows(e->da, B, x, 576, nullptr, T, 0, s); }
     e->cur_B = B;
     e->cur_pos = T;
     e->h_pos_word = T - 1;
@@ -1182,7 +1204,7 @@ static int encode_pair_to_prefix(mellow_engine* e, const float* a1, const float*
     HIPCHK(hipMemcpyAsync(cat.p + (size_t)B * n_samples, a2, (size_t)B * n_samples * 4, hipMemcpyDeviceToDevice, e->stream));
     CHK(run_encoder(e, cat.p, 2 * B, n_samples, 0, 1, nullptr));
     { ProfScope ps(e, PF_MISC, 0, 0);
-      launch_prefix_assemble(e->proj33.p, e->embed, ids, B, e->cfg.text_len, e->cfg.sep_token_id, prefix_out, e->stream); }
+      launch_prefix_assemble(e->proj33.p, e->embed, ids, B, e->cfg.text_len, e->cfg.sep_token_id, e->cfg.vocab_size, prefix_out, e->stream); }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1218,7 +1240,7 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
     if (e->cur_pos + 1 > e->kv_Tmax) return fail("KV pages exhausted (reserve too small)");
     HIPCHK(hipSetDevice(e->device));
     const int B = e->cur_B;
-    launch_dec_load_rows(e->da, B, e->embed, 576, token_ids, 0, e->stream);
+    launch_dec_load_rows(e->da, B, e->embed, 576, token_ids, 0, e->cfg.vocab_size, e->stream);
     CHK(enqueue_decode_layers(e, B, nullptr));   // its first kernel advances the device position word
     e->cur_pos += 1;
     if (logits)
@@ -1245,28 +1267,34 @@ int mellow_resample(mellow_engine_t* e, const float* wav, int n_clips, int64_t n
     const double base_freq = (orig < nw ? orig : nw) * rolloff;
     const int width = (int)std::ceil(lpw * orig / base_freq);
     const int klen = 2 * width + orig;
-    std::vector<float> wT((size_t)klen * nw);
-    const double scale = base_freq / orig;
-    for (int p = 0; p < nw; ++p)
-        for (int k = 0; k < klen; ++k) {
-            double t = (double)(-p) / nw + (double)(k - width) / orig;
-            t *= base_freq;
-            if (t < -lpw) t = -lpw;
-            if (t > lpw) t = lpw;
-            const double c = std::cos(t * PI / lpw / 2.0);
-            const double window = c * c;
-            t *= PI;
-            const double kern = t == 0.0 ? 1.0 : std::sin(t) / t;
-            wT[(size_t)k * nw + p] = (float)(kern * window * scale);
-        }
     float* dw = nullptr;
-    HIPCHK(hipMalloc(&dw, wT.size() * sizeof(float)));
-    HIPCHK(hipMemcpyAsync(dw, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    auto it = e->resample_banks.find({orig, nw});
+    if (it != e->resample_banks.end()) {
+        dw = it->second;
+    } else {    // built once per rate pair and kept (no allocation / host filter design on later calls)
+        std::vector<float> wT((size_t)klen * nw);
+        const double scale = base_freq / orig;
+        for (int p = 0; p < nw; ++p)
+            for (int k = 0; k < klen; ++k) {
+                double t = (double)(-p) / nw + (double)(k - width) / orig;
+                t *= base_freq;
+                if (t < -lpw) t = -lpw;
+                if (t > lpw) t = lpw;
+                const double c = std::cos(t * PI / lpw / 2.0);
+                const double window = c * c;
+                t *= PI;
+                const double kern = t == 0.0 ? 1.0 : std::sin(t) / t;
+                wT[(size_t)k * nw + p] = (float)(kern * window * scale);
+            }
+        HIPCHK(hipMalloc(&dw, wT.size() * sizeof(float)));
+        e->allocs.push_back(dw);
+        HIPCHK(hipMemcpy(dw, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+        e->resample_banks[{orig, nw}] = dw;
+    }
     // rows of `out` are `target` long: the kernel writes with stride n_out = target
     launch_resample(wav, n_clips, n_in, dw, orig, nw, klen, width, out, target, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipFree(dw));
     return 0;
 }
 
@@ -1283,34 +1311,67 @@ int mellow_argmax(mellow_engine_t* e, const float* logits, int B, int32_t* token
 
 extern "C" {
 
+// Wait (without touching the stream) until the arg-max kernel has published ticket >= want; *nseen = rows stopped so far.
+static int wait_ticket(mellow_engine* e, unsigned want, unsigned* nseen) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long v = __atomic_load_n(e->h_progress, __ATOMIC_ACQUIRE);
+        if ((unsigned)(v >> 32) >= want) {
+            if (nseen) *nseen = (unsigned)(v & 0xffffffffu);
+            return 0;
+        }
+        if ((spins & 0x3ff) == 0) {
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) {      // nothing left in flight: the ticket must be there now
+                const unsigned long long v2 = __atomic_load_n(e->h_progress, __ATOMIC_ACQUIRE);
+                if ((unsigned)(v2 >> 32) >= want) continue;
+                return fail("decode progress word stalled at ticket %u (wanted %u) with an idle stream", (unsigned)(v2 >> 32), want);
+            }
+            if (q != hipErrorNotReady) return fail("stream error while waiting for a decode step: %s", hipGetErrorString(q));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                return fail("timed out waiting for decode ticket %u", want);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
                     const int32_t* input_ids, int B, int max_len, float top_p, float temperature, int stop_id,
                     int ignore_stop, int32_t* out_tokens, int32_t* out_len, int32_t* out_steps, float* first_token_ms) {
     (void)top_p;
     (void)temperature;  // the reference's top-p/temperature path never changes the arg-max (wrapper.py:219-232)
+    const auto t_entry = std::chrono::steady_clock::now();
     if (!e || !e->finalized) return fail("engine not finalized");
     if (!audio1 || !audio2 || !input_ids || !out_tokens) return fail("null argument");
     if (B <= 0 || max_len <= 0) return fail("B and max_len must be positive");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int T = e->cfg.prefix_len;
-    CHK(ensure_lm(e, B, T, T + max_len));
+    // KV page geometry in buckets of 64 positions, so that nearby max_len values share pages, key split and graphs
+    int Tmax = rup(T + max_len, 64);
+    if (Tmax > e->cfg.max_positions || Tmax > 2048) Tmax = T + max_len;
+    CHK(ensure_lm(e, B, T, Tmax));
+    const int Bp = e->da.rows;
+    CHK(ensure(e, e->out_tok, (size_t)Bp * max_len));
     HIPCHK(hipEventRecord(e->ev_phase[0], s));
-    // loop state (the prefill's arg-max already records token 0)
-    HIPCHK(hipMemsetAsync(e->d_nseen, 0, sizeof(int32_t), s));
+    // loop state (the prefill's arg-max already records token 0 and publishes ticket 1)
+    __atomic_store_n(e->h_progress, 0ull, __ATOMIC_RELEASE);
+    HIPCHK(hipMemsetAsync(e->d_nseen, 0, 3 * sizeof(int32_t), s));       // n_seen, arrive, ticket
     HIPCHK(hipMemsetAsync(e->d_seen, 0, 1024 * sizeof(int32_t), s));
+    e->h_params[0] = max_len;
+    e->h_params[1] = stop_id;
+    HIPCHK(hipMemcpyAsync(e->d_params, e->h_params, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
     HIPCHK(hipEventRecord(e->ev_phase[1], s));
     RecordArgs rec;
-    rec.out_tokens = out_tokens; rec.max_len = max_len; rec.stop_id = stop_id; rec.embed_next = true;
+    rec.embed_next = true;
     CHK(run_prefill(e, B, T, &rec));
     HIPCHK(hipEventRecord(e->ev_phase[2], s));
 
-    // one decode step = 30 x (finish | qkv | attention | o_proj | finish | gate/up | down) + finish + lm_head +
-    // arg-max/record/embed, captured once per (B, Tmax, out buffer, max_len, stop id) and replayed
+    // one decode step = 30 x (qkv | attention | o_proj | gate/up | down) + final norm + lm_head + arg-max/record/embed,
+    // captured once per (B, page geometry, buffers) and replayed; max_len and the stop id are read from d_params
     const bool graph = e->use_graph && !e->prof_on && max_len > 1;
-    if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tokens != out_tokens ||
-                  e->graph_max_len != max_len || e->graph_stop != stop_id)) {
+    if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tok != e->out_tok.p)) {
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
         if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         hipGraph_t gr = nullptr;
@@ -1323,46 +1384,60 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         HIPCHK(hipGraphDestroy(gr));
         // eight consecutive steps as ONE graph: the step reads its position from the device word, so a replay of the
         // same kernel sequence IS the next step; one launch per 8 steps removes the host/CP hand-over between graphs
-        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
-        if (max_len > 8) {
-            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            int rc8 = 0;
-            for (int k = 0; k < 8 && !rc8; ++k) rc8 = enqueue_decode_layers(e, B, &rec);
-            hipError_t ce8 = hipStreamEndCapture(s, &gr);
-            if (rc8) return rc8;
-            if (ce8 != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce8));
-            HIPCHK(hipGraphInstantiate(&e->step_exec8, gr, nullptr, nullptr, 0));
-            HIPCHK(hipGraphDestroy(gr));
-        }
-        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tokens = out_tokens; e->graph_max_len = max_len;
-        e->graph_stop = stop_id;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc8 = 0;
+        for (int k = 0; k < 8 && !rc8; ++k) rc8 = enqueue_decode_layers(e, B, &rec);
+        hipError_t ce8 = hipStreamEndCapture(s, &gr);
+        if (rc8) return rc8;
+        if (ce8 != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce8));
+        HIPCHK(hipGraphInstantiate(&e->step_exec8, gr, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(gr));
+        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tok = e->out_tok.p;
     }
     int steps_done = 1;   // token 0 came from the prefill
-    for (int i = 1; i < max_len;) {
-        // stop checks happen after steps 7, 15, ... (i % 8 == 7): an 8-step graph may run from i to i+7 when it ends on one
-        const bool eight = graph && e->step_exec8 && i + 8 <= max_len && (ignore_stop || (i + 7) % 8 == 7);
-        const int n_adv = eight ? 8 : 1;
-        if (eight) HIPCHK(hipGraphLaunch(e->step_exec8, s));
-        else if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
-        else CHK(enqueue_decode_layers(e, B, &rec));
-        i += n_adv;
-        e->cur_pos += n_adv;
-        steps_done = i;
-        if (!ignore_stop && ((i - 1) % 8) == 7) {
-            int32_t seen = 0;
-            HIPCHK(hipMemcpyAsync(&seen, e->d_nseen, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (seen >= B) break;
+    double first_ms = -1.0;
+    auto note_first = [&]() {
+        if (first_ms < 0) first_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+    };
+    if (ignore_stop) {
+        // fixed-length mode: nothing to decide on the host, everything is enqueued at once
+        for (int i = 1; i < max_len;) {
+            const bool eight = graph && i + 8 <= max_len;
+            if (eight) HIPCHK(hipGraphLaunch(e->step_exec8, s));
+            else if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
+            else CHK(enqueue_decode_layers(e, B, &rec));
+            i += eight ? 8 : 1;
+            e->cur_pos += eight ? 8 : 1;
+            steps_done = i;
         }
+        CHK(wait_ticket(e, 1, nullptr));
+        note_first();
+    } else {
+        // reference stop rule (wrapper.py:247-249): the loop ends after the first step at which every row has produced the
+        // stop id at least once.  The arg-max kernel publishes (step ticket, rows stopped) to a host-visible word, so the
+        // host follows the rule one step behind the device without synchronising: step i+1 is enqueued while step i runs,
+        // and at most ONE step is ever enqueued past the deciding one.
+        for (int i = 1; i < max_len; ++i) {
+            if (graph) HIPCHK(hipGraphLaunch(e->step_exec, s));
+            else CHK(enqueue_decode_layers(e, B, &rec));
+            e->cur_pos += 1;
+            steps_done = i + 1;
+            unsigned nseen = 0;
+            CHK(wait_ticket(e, (unsigned)i, &nseen));      // ticket i = the arg-max of step index i-1 is complete
+            note_first();
+            if ((int)nseen >= B) break;
+        }
+        if (first_ms < 0) { CHK(wait_ticket(e, 1, nullptr)); note_first(); }
     }
     HIPCHK(hipEventRecord(e->ev_phase[3], s));
     HIPCHK(hipGetLastError());
+    // host-side length bookkeeping (reference wrapper.py:247-254) on the engine-owned record
+    std::vector<int32_t> toks((size_t)B * max_len);
+    HIPCHK(hipMemcpyAsync(out_tokens, e->out_tok.p, toks.size() * sizeof(int32_t), hipMemcpyDefault, s));
+    HIPCHK(hipMemcpyAsync(toks.data(), e->out_tok.p, toks.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&e->phase_ms[i], e->ev_phase[i], e->ev_phase[i + 1]));
-    if (first_token_ms) *first_token_ms = e->phase_ms[0] + e->phase_ms[1];
-    // host-side length bookkeeping (reference wrapper.py:247-254)
-    std::vector<int32_t> toks((size_t)B * max_len);
-    HIPCHK(hipMemcpy(toks.data(), out_tokens, toks.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (first_token_ms) *first_token_ms = (float)first_ms;
     int ref_steps = steps_done;
     if (!ignore_stop) {
         // the reference stops after the first step at which every row has produced stop_id at least once
@@ -1374,6 +1449,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
             if (nseen == B) { ref_steps = st + 1; break; }
         }
     }
+    e->last_steps_enqueued = steps_done;
     if (out_steps) *out_steps = ref_steps;
     if (out_len)
         for (int b = 0; b < B; ++b) {
@@ -1384,6 +1460,8 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         }
     return 0;
 }
+
+int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_enqueued : -1; }
 
 int mellow_prof_enable(mellow_engine_t* e, int on) {
     if (!e) return fail("null engine");

@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float x = ni == 0 ? x1[j] : x2[j];
-                            x = fmaxf(x, 1e-10f);
+                            x = x < 1e-10f ? 1e-10f : x;      // torch.clamp(min=1e-10): NaN stays NaN (fmaxf would drop it)
                             x = __fmul_rn(10.0f, log10f(x));
                             if (g.apply_bn) x = __fadd_rn(__fmul_rn(x, g.bn_alpha[col + j]), g.bn_beta[col + j]);
                             v[j] = x;

@@ -121,14 +121,27 @@ void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStre
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s);
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s);
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s);
-// per-row arg-max over the lm_head candidates; records at column (*d_pos - T0 + 1) when out_tokens != null, tracks
-// stop ids, and (write_x) gathers embed[token] as the next step's residual stream
+// Generation-loop bookkeeping that lives on the device (reference wrapper.py:232-249), written by the arg-max kernel:
+// the token is recorded at column (*d_pos - T0 + 1) of out_tokens, rows that produced the stop id are counted once, and
+// the LAST row to arrive publishes (step ticket << 32 | rows that have stopped) to a host-visible word, so the host
+// loop follows the stop rule without ever synchronising the stream.
+struct LoopArgs {
+    int32_t* out_tokens = nullptr;       // engine-owned [rows][params[0]] (null: taps / single-step calls record nothing)
+    const int32_t* params = nullptr;     // device {max_len, stop_id}: graph replays serve any value
+    int32_t* seen_stop = nullptr;        // [rows] 0/1
+    int32_t* n_seen = nullptr;
+    int32_t* arrive = nullptr;           // rows that finished this step's arg-max (reset by the last one)
+    int32_t* ticket = nullptr;           // arg-max launches since the start of the call
+    unsigned long long* host_progress = nullptr;   // mapped host memory
+    int T0 = 0;                          // prefix length
+};
+// per-row arg-max over the lm_head candidates (torch.argmax order: NaN = maximum, lowest index on ties); with
+// write_x it gathers embed[token] as the next step's residual stream
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
-                       int32_t* out_tokens, int max_len, int T0, int stop_id, int32_t* seen_stop, int32_t* n_seen,
-                       hipStream_t s);
+                       const LoopArgs& loop, hipStream_t s);
 // residual stream <- rows of `in`: row_ids[b] (embedding gather) or, when row_ids == null, row b*T_last + T_last-1
 void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
-                          hipStream_t s);
+                          int n_src /* rows of `in` that row_ids may address */, hipStream_t s);
 void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s);
 // developer instrumentation: device buffer of 64 uint64 slots stamped by workgroup 0 of the decode kernels (null = off)
 void set_kernel_debug_buffer(uint64_t* p);
@@ -171,7 +184,7 @@ void launch_crop_average(const float* in, int n, int n_crops, int64_t len, int64
 void launch_gelu(const float* in, float* out, int64_t n, hipStream_t s);
 // prefix [B][389][576] from proj33 [2B][33][576] (clips 0..B-1 = audio1, B..2B-1 = audio2)
 void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
-                            int sep_id, float* prefix, hipStream_t s);
+                            int sep_id, int vocab, float* prefix, hipStream_t s);
 // audio129 [n][129][576] from proj33 [n][33][576] (tap / mellow_encode)
 void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 

@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None):
         "mellow_prof_family_name": (C.c_char_p, [ci]),
         "mellow_prof_get": (ci, [vp, ci, P(i64), P(C.c_double), P(C.c_double), P(C.c_double)]),
         "mellow_last_phase_ms": (ci, [vp, P(cf), P(cf), P(cf)]),
+        "mellow_last_steps_enqueued": (ci, [vp]),
         "mellow_engine_set_precision": (ci, [vp, ci]),
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = (
     "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
-    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms",
+    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued",
     "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
 )
 
@@ -124,7 +125,7 @@ def _ptr(t: torch.Tensor) -> C.c_void_p:
 class Engine:
     """One engine per device.  Inputs/outputs are torch tensors on that device (plumbing only)."""
 
-    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 1024,
+    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 2048,
                  precision: str = "f32"):
         self.lib = load_library()
         if self.lib.mellow_device_count() <= 0:
@@ -206,14 +207,37 @@ class Engine:
         t = torch.as_tensor(x)
         return t.to(device=self.tdev, dtype=torch.int32).contiguous()
 
+    def _ids(self, x) -> torch.Tensor:
+        """token ids -> int32 on the device; ids outside the vocabulary raise like the reference's embedding lookup
+        (`lm.model.embed_tokens`, decoder.py:47 / wrapper.py:237) instead of reaching a kernel."""
+        t = torch.as_tensor(x)
+        if t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.lm.vocab_size):
+            raise IndexError("index out of range in self")
+        return t.to(device=self.tdev, dtype=torch.int32).contiguous()
+
+    def _sync_inputs(self):
+        """The engine runs on its own non-blocking HIP stream: device tensors produced by still-running torch kernels
+        (resample / tile / cat on torch's current stream) must be complete before their raw pointers cross the C ABI."""
+        torch.cuda.current_stream(self.tdev).synchronize()
+
+    def max_new_tokens_limit(self) -> int:
+        """largest max_len the KV pages / RoPE tables of this engine can hold"""
+        return min(int(self.cfg.max_positions), 2048) - spec.PREFIX_LEN
+
     # ---- hot path ----------------------------------------------------------------------------------
     def generate(self, audio1, audio2, input_ids, max_len: int, top_p: float = 0.8, temperature: float = 1.0,
                  stop_id: int = 0, ignore_stop: bool = False):
-        """-> (tokens int32 [B, steps] on host, lengths [B], steps, first_token_ms)"""
-        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._i32(input_ids)
+        """-> (tokens int32 [B, steps] on host, lengths [B], steps, first_token_ms)
+        first_token_ms is measured from the C entry (inputs on the device); `last_first_token_host_ms` adds the time this
+        call spent bringing host arrays to the device (latency from audio in HOST memory)."""
+        import time
+        t_in = time.perf_counter()
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._ids(input_ids)
         B, n = a1.shape
         assert a2.shape == a1.shape and ids.shape == (B, spec.TEXT_LEN), (a1.shape, a2.shape, ids.shape)
         out = torch.empty((B, max_len), dtype=torch.int32, device=self.tdev)
+        self._sync_inputs()
+        t_up = (time.perf_counter() - t_in) * 1e3
         lens = (C.c_int32 * B)()
         steps = C.c_int32(0)
         ftm = C.c_float(0.0)
@@ -221,13 +245,18 @@ class Engine:
                                            float(temperature), int(stop_id), 1 if ignore_stop else 0, _ptr(out),
                                            lens, C.byref(steps), C.byref(ftm)))
         toks = out.cpu().numpy()[:, : steps.value]
+        self.last_first_token_host_ms = t_up + float(ftm.value)
         return toks, np.asarray(list(lens), dtype=np.int32), int(steps.value), float(ftm.value)
+
+    def last_steps_enqueued(self) -> int:
+        return int(self.lib.mellow_last_steps_enqueued(self.h))
 
     # ---- taps ----------------------------------------------------------------------------------------
     def logmel(self, wav, apply_bn: bool = False) -> torch.Tensor:
         w = self._f32(wav)
         n, ns = w.shape
         out = torch.empty((n, spec.frames_for(ns), spec.MEL_BINS), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_logmel(self.h, _ptr(w), n, ns, 1 if apply_bn else 0, _ptr(out)))
         return out
 
@@ -235,13 +264,15 @@ class Engine:
         w = self._f32(wav)
         n, ns = w.shape
         out = torch.empty((n, spec.AUDIO_ROWS, spec.D_PROJ), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_encode(self.h, _ptr(w), n, ns, _ptr(out)))
         return out
 
     def prefix(self, audio1, audio2, input_ids) -> torch.Tensor:
-        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._i32(input_ids)
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._ids(input_ids)
         B, n = a1.shape
         out = torch.empty((B, spec.PREFIX_LEN, spec.D_PROJ), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_prefix(self.h, _ptr(a1), _ptr(a2), n, _ptr(ids), B, _ptr(out)))
         return out
 
@@ -249,18 +280,21 @@ class Engine:
         p = self._f32(prefix)
         B, T, H = p.shape
         out = torch.empty((B, self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_lm_prefill(self.h, _ptr(p), B, T, int(reserve), _ptr(out)))
         return out
 
     def lm_decode_step(self, token_ids) -> torch.Tensor:
-        t = self._i32(token_ids).reshape(-1)
+        t = self._ids(token_ids).reshape(-1)
         out = torch.empty((t.shape[0], self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_lm_decode_step(self.h, _ptr(t), _ptr(out)))
         return out
 
     def argmax(self, logits) -> torch.Tensor:
         l = self._f32(logits)
         out = torch.empty((l.shape[0],), dtype=torch.int32, device=self.tdev)
+        self._sync_inputs()
         self._chk(self.lib.mellow_argmax(self.h, _ptr(l), l.shape[0], _ptr(out)))
         return out
 
@@ -271,6 +305,7 @@ class Engine:
             w = w[None]
         n, n_in = w.shape
         n_out = C.c_int64(0)
+        self._sync_inputs()
         self._chk(self.lib.mellow_resample(self.h, _ptr(w), n, n_in, int(orig_freq), int(new_freq), None, 0, C.byref(n_out)))
         out = torch.empty((n, n_out.value), dtype=torch.float32, device=self.tdev)
         self._chk(self.lib.mellow_resample(self.h, _ptr(w), n, n_in, int(orig_freq), int(new_freq), _ptr(out), n_out.value,

@@ -198,3 +198,9 @@ def make_batch(B: int, n_samples: int = 320000, first: int = 0, vocab: int = 491
     a2 = np.stack([make_clip(2 * (first + i) + 1, n_samples) for i in range(B)])
     ids = np.stack([make_prompt_ids(first + i, vocab=vocab) for i in range(B)])
     return a1, a2, ids
+
+
+def make_examples(indices, n_samples: int = 320000, vocab: int = 49152):
+    """The same as make_batch for an arbitrary list of example indices (rows in the given order)."""
+    parts = [make_batch(1, n_samples=n_samples, first=int(i), vocab=vocab) for i in indices]
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))

@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import math
 import os
+import warnings
 from collections import OrderedDict
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
@@ -58,7 +59,13 @@ class MellowWrapper:
     model_name = {"v0": "v0.ckpt", "v0_s": "v0_s.ckpt"}
 
     def __init__(self, config, model, device, use_cuda=True, *, checkpoint: Optional[str] = None,
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: int = 1024):
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: int = 2048,
+                 data_parallel: Optional[bool] = None):
+        """Reference signature `MellowWrapper(config, model, device, use_cuda=True)` (wrapper.py:35) plus keyword-only
+        extensions: `checkpoint` (a local .ckpt instead of the hub download), `state_dict` (already loaded), `tokenizer`
+        (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; the decode
+        attention supports 2048 keys), `data_parallel` (None: shard `generate` over the ranks of an initialised
+        torch.distributed group, one process per GPU; False: never)."""
         self.supported_versions = self.model_name.keys()
         if model not in self.supported_versions:
             raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
@@ -70,6 +77,7 @@ class MellowWrapper:
         self.model_path = self._resolve_checkpoint(model, checkpoint) if state_dict is None else "<state_dict>"
         self._tokenizer_override = tokenizer
         self._max_positions = max_positions
+        self._data_parallel = data_parallel
         self.model, self.tokenizer, self.args = self.get_model_and_tokenizer(config_path=self.config_path)
 
     # ---- construction -------------------------------------------------------------------------------------
@@ -181,13 +189,47 @@ class MellowWrapper:
         return {"input_ids": torch.stack(ids, 0), "attention_mask": torch.stack(masks, 0)}
 
     # ---- generation ---------------------------------------------------------------------------------------------
+    def _dp(self):
+        """(rank, world) of the data-parallel group `generate` shards over, (0, 1) when not distributed."""
+        import torch.distributed as dist
+        if self._data_parallel is False or os.environ.get("MELLOW_DATA_PARALLEL") == "0":
+            return 0, 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _clamp_max_len(self, entry_length: int) -> int:
+        limit = self.model.max_new_tokens_limit()
+        if entry_length > limit:
+            # the reference treats max_len as a safety bound (the loop normally ends at the stop token, wrapper.py:247-249)
+            warnings.warn(f"max_len {entry_length} exceeds what the engine's KV pages hold (prefix {spec.PREFIX_LEN} + "
+                          f"max_len <= {limit + spec.PREFIX_LEN}); clamped to {limit}")
+            return limit
+        return entry_length
+
     def _generate_batch(self, audio1, audio2, input_ids, entry_length=300, top_p=0.8, temperature=1.0,
-                        stop_token: str = "<|endoftext|>"):
+                        stop_token: str = "<|endoftext|>", n_total: Optional[int] = None):
+        """Tokens for the rows given (this rank's shard under data parallelism), decoded for ALL `n_total` examples:
+        the shards' token ids are all-gathered once (mellow_amd.dist, RCCL over xGMI under backend "nccl")."""
         stop_token_index = self.tokenizer.encode(stop_token)[0]
-        toks, lens, steps, ftm = self.model.generate(audio1, audio2, input_ids, max_len=entry_length, top_p=top_p,
-                                                     temperature=temperature, stop_id=stop_token_index)
-        self.last_first_token_ms = ftm
-        return [self.tokenizer.decode(x).split("<|endoftext|>")[0] for x in toks]
+        entry_length = self._clamp_max_len(int(entry_length))
+        rank, world = self._dp()
+        n_local = int(audio1.shape[0])
+        if n_local:
+            toks, lens, steps, ftm = self.model.generate(audio1, audio2, input_ids, max_len=entry_length, top_p=top_p,
+                                                         temperature=temperature, stop_id=stop_token_index)
+            self.last_first_token_ms = ftm
+        else:
+            toks, lens = np.zeros((0, 0), dtype=np.int32), np.zeros((0,), dtype=np.int32)
+        if world > 1:
+            import torch.distributed as dist
+            from . import dist as mdist
+            dev = self.model.tdev if dist.get_backend() == "nccl" else torch.device("cpu")
+            toks, lens = mdist.gather_tokens(toks, lens, int(n_total), entry_length, device=dev)
+            rows = [r[r >= 0] for r in toks]          # -1 = padding of shards that stopped earlier
+        else:
+            rows = list(toks)
+        return [self.tokenizer.decode(x).split("<|endoftext|>")[0] for x in rows]
 
     def generate(self, examples, max_len, top_p, temperature, stop_token="<|endoftext|>", audio_resample=True):
         r"""Produces text response for the given audio files and text prompts
@@ -195,15 +237,29 @@ class MellowWrapper:
         max_len: (int) maximum length for text generation
         top_p, temperature: accepted for API parity; decoding is greedy (see module docstring)
         stop_token: (str) token used to stop text generation
-        audio_resample (bool) True for resampling audio. The model supports only 32 kHz"""
+        audio_resample (bool) True for resampling audio. The model supports only 32 kHz
+
+        Under an initialised torch.distributed group (one process per GPU, every rank calling with the same examples)
+        the examples are sharded contiguously over the ranks, each rank ingests and runs only its shard, and every rank
+        returns the full list."""
         audio_paths1, audio_paths2, text_prompts = [], [], []
         for example in examples:
             ap1, ap2, tp = example
             audio_paths1.append(ap1)
             audio_paths2.append(ap2)
             text_prompts.append(tp)
-        audio1 = self.preprocess_audio(audio_paths1, resample=audio_resample)
-        audio2 = self.preprocess_audio(audio_paths2, resample=audio_resample)
-        text = self.preprocess_text(text_prompts)
-        return self._generate_batch(audio1, audio2, text["input_ids"], entry_length=max_len, top_p=top_p,
-                                    temperature=temperature, stop_token=stop_token)
+        rank, world = self._dp()
+        n = len(examples)
+        lo, hi = 0, n
+        if world > 1:
+            from .dist import shard_range
+            lo, hi = shard_range(n, rank, world)
+        if hi > lo:
+            audio1 = self.preprocess_audio(audio_paths1[lo:hi], resample=audio_resample)
+            audio2 = self.preprocess_audio(audio_paths2[lo:hi], resample=audio_resample)
+            ids = self.preprocess_text(text_prompts[lo:hi])["input_ids"]
+        else:
+            audio1 = audio2 = torch.zeros((0, 1))
+            ids = torch.zeros((0, spec.TEXT_LEN), dtype=torch.int64)
+        return self._generate_batch(audio1, audio2, ids, entry_length=max_len, top_p=top_p,
+                                    temperature=temperature, stop_token=stop_token, n_total=n)

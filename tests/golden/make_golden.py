@@ -116,11 +116,147 @@ def maxdiff(a, b):
     return float((a - b).abs().max()), float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def gen_case(args, model, sd, lmp, prefix, B, t0):
+    # ------------------------------------------------------------------ case "gen": greedy tokens + logits
+    with torch.no_grad():
+        strings, toks, logits_log = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0)
+        strings2, toks2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0, top_p=0.1, temperature=0.3)
+    toks = np.asarray(toks, dtype=np.int64)
+    assert np.array_equal(toks, np.asarray(toks2)), "sampling params changed greedy result (SURVEY A16)"
+    L = torch.stack(logits_log)                                             # (steps,B,V)
+    top2 = torch.topk(L, 2, dim=-1).values
+    gaps = (top2[..., 0] - top2[..., 1]).numpy()
+    print(f"reference tokens ({time.time() - t0:.1f}s):\n{toks}\nmin top-2 gap {gaps.min():.4f}")
+    rec = {}
+    with torch.no_grad():
+        otoks = O.generate_batch(sd, lmp, prefix, N_STEPS, 0.8, 1.0, 0, record=rec).numpy()
+    assert np.array_equal(otoks, toks), (otoks, toks)
+    d = maxdiff(torch.stack(rec["logits"]), L)
+    print(f"oracle logits vs reference: {d[0]:.3e} abs")
+    assert d[0] < 2e-3
+
+    # EOS semantics: stop id := token row 0 produced at step 3 -> B=1 run must break right after it
+    stop = int(toks[0, 3])
+    with torch.no_grad():
+        s_eos, t_eos, _ = ref_generate_tokens(model, prefix[:1], N_STEPS, stop_id=stop)
+        s_eos2, t_eos2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=stop)
+    print("eos case:", stop, t_eos, [len(t) for t in t_eos2])
+    np.savez_compressed(
+        os.path.join(args.out, "gen.npz"),
+        seed=SEED, B=B, steps=N_STEPS, tokens=toks, logits_sub=L[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB,
+        logits_step0=L[0].numpy(), top2_gap=gaps,
+        eos_stop_id=stop, eos_b1_tokens=np.asarray(t_eos[0], dtype=np.int64),
+        eos_b2_len=np.asarray([len(t) for t in t_eos2], dtype=np.int64),
+        eos_b2_row0=np.asarray(t_eos2[0], dtype=np.int64), eos_b2_row1=np.asarray(t_eos2[1], dtype=np.int64),
+    )
+
+
+
+def long30_case(args, model, sd):
+    # ------------------------------------------------------------------ case "long30": 30 s -> 7 crops
+    if True:
+        a30 = torch.from_numpy(synth.make_clip(900, 960000))[None]
+        with torch.no_grad():
+            proj_ref, _, od = model.audio_encoder(a30)
+            ot = {}
+            proj_or = O.audio_encoder(sd, a30, ot)
+        d = maxdiff(proj_or, proj_ref)
+        print(f"long30: crops={ot.get('n_crops')} oracle vs reference projected {d[0]:.3e}")
+        assert ot["n_crops"] == 7 and d[1] < 1e-4
+        fw = od["framewise_output"]
+        np.savez_compressed(
+            os.path.join(args.out, "long30.npz"),
+            clip_idx=900, n_samples=960000, n_crops=7,
+            latent=od["latent_output"].numpy(), framewise32=fw[:, 0::32, :].numpy(),
+            audio_ds=O.downsample(proj_ref).numpy(),
+        )
+
+
+LATE_STEPS = 300
+LATE_KEEP = (63, 150, 299)          # step index i <-> context T = 389 + i keys (452, 539, 688)
+
+
+def late_case(args, model, prefix, t0):
+    """Late positions: the reference's own loop for 300 steps at B=2 (contexts 389..688, beyond one
+    448-key attention chunk of the HIP decode kernel and at BASELINE config 3's max_len).  Stored: every greedy token, the
+    top-2 logit gap of every step, and sub-sampled last-position logits of steps 63 / 150 / 299."""
+    with torch.no_grad():
+        _, toks, logits_log = ref_generate_tokens(model, prefix, LATE_STEPS, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    assert toks.shape == (prefix.shape[0], LATE_STEPS), toks.shape
+    gaps = np.stack([(lambda t2: (t2[..., 0] - t2[..., 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in logits_log])
+    print(f"late: {LATE_STEPS} reference steps ({time.time() - t0:.1f}s); min top-2 gap {gaps.min():.4f} at step "
+          f"{int(np.argmin(gaps.min(1)))}; tokens[:, -5:] = {toks[:, -5:].tolist()}")
+    g12 = np.load(os.path.join(args.out, "gen.npz"))["tokens"]
+    assert np.array_equal(toks[:, : g12.shape[1]], g12)
+    np.savez_compressed(
+        os.path.join(args.out, "late.npz"),
+        seed=SEED, B=toks.shape[0], steps=LATE_STEPS, tokens=toks, top2_gap=gaps.astype(np.float32),
+        keep_steps=np.asarray(LATE_KEEP), sub_vocab=SUB_VOCAB,
+        logits_sub=torch.stack([logits_log[i][:, SUB_VOCAB] for i in LATE_KEEP]).numpy(),
+        logits_max=torch.stack([logits_log[i].max(-1).values for i in LATE_KEEP]).numpy(),
+    )
+
+
+def _examples(idx):
+    return synth.make_examples(idx)
+
+
+RAGGED_EXAMPLES = (0, 1, 2)
+EOS_EXAMPLES = (1, 2, 4, 3)         # rows that emit EOS_STOP at steps 8 / 17 / 3 / never (within 20 steps)
+EOS_STOP = 42274
+EOS_MAXLEN = 24
+
+
+def ragged_eos_cases(args, model, sd, lmp, t0, want):
+    """B=3 (not a multiple of anything) greedy tokens, and the reference's stop rule with rows that hit the stop id at
+    different steps (wrapper.py:241-254): the loop ends after the first step at which every row has produced it."""
+    idx = sorted(set(RAGGED_EXAMPLES) | set(EOS_EXAMPLES))
+    a1, a2, ids = _examples(idx)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
+                                                        "input": {"input_ids": torch.from_numpy(ids)}})
+    pos = {e: i for i, e in enumerate(idx)}
+    if want("ragged"):
+        p3 = prefix[[pos[e] for e in RAGGED_EXAMPLES]]
+        with torch.no_grad():
+            _, toks, logits_log = ref_generate_tokens(model, p3, N_STEPS, stop_id=-1)
+        toks = np.asarray(toks, dtype=np.int64)
+        print(f"ragged B=3 ({time.time() - t0:.1f}s):\n{toks}")
+        np.savez_compressed(os.path.join(args.out, "ragged3.npz"), examples=np.asarray(RAGGED_EXAMPLES), steps=N_STEPS,
+                            tokens=toks, prefix_row2=p3[2].numpy(),
+                            logits_sub=torch.stack(logits_log)[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB)
+    if want("eos"):
+        out = {}
+        for name, rows in (("all_stop", EOS_EXAMPLES[:3]), ("one_never", EOS_EXAMPLES)):
+            p = prefix[[pos[e] for e in rows]]
+            with torch.no_grad():
+                strings, toks, logits_log = ref_generate_tokens(model, p, EOS_MAXLEN, stop_id=EOS_STOP)
+                _, free, _ = ref_generate_tokens(model, p, EOS_MAXLEN, stop_id=-1)
+            n_steps = len(logits_log)
+            lens = [len(t) for t in toks]
+            print(f"eos {name}: rows {rows} steps run {n_steps} lengths {lens} ({time.time() - t0:.1f}s)")
+            out[f"{name}_examples"] = np.asarray(rows)
+            out[f"{name}_steps"] = n_steps
+            out[f"{name}_len"] = np.asarray(lens, dtype=np.int64)
+            out[f"{name}_free_tokens"] = np.asarray(free, dtype=np.int64)          # the same rows with no stop id
+            for r, t in enumerate(toks):
+                out[f"{name}_row{r}"] = np.asarray(t, dtype=np.int64)
+        assert out["all_stop_steps"] < EOS_MAXLEN and len(set(out["all_stop_len"].tolist())) == 3
+        np.savez_compressed(os.path.join(args.out, "eos_mixed.npz"), stop_id=EOS_STOP, max_len=EOS_MAXLEN, **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos "
+                                               "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+
+    def want(case):
+        return not only or case in only
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     t0 = time.time()
@@ -182,7 +318,8 @@ def main():
     tok_idx = np.arange(0, 4096, 41)       # 100 patch tokens
     fw = od1["framewise_output"]
     assert torch.equal(fw[:, 0::32, :].repeat_interleave(32, dim=1), fw)   # only 32 distinct rows
-    np.savez_compressed(
+    if want("enc10"):
+      np.savez_compressed(
         os.path.join(args.out, "enc10.npz"),
         seed=SEED, B=B,
         power_sub=taps["power"][:, 0, ::50, ::8].numpy(),                  # (B,21,65)
@@ -200,56 +337,14 @@ def main():
         prefix=prefix.numpy(),                                              # (B,389,576)
     )
 
-    # ------------------------------------------------------------------ case "gen": greedy tokens + logits
-    with torch.no_grad():
-        strings, toks, logits_log = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0)
-        strings2, toks2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=0, top_p=0.1, temperature=0.3)
-    toks = np.asarray(toks, dtype=np.int64)
-    assert np.array_equal(toks, np.asarray(toks2)), "sampling params changed greedy result (SURVEY A16)"
-    L = torch.stack(logits_log)                                             # (steps,B,V)
-    top2 = torch.topk(L, 2, dim=-1).values
-    gaps = (top2[..., 0] - top2[..., 1]).numpy()
-    print(f"reference tokens ({time.time() - t0:.1f}s):\n{toks}\nmin top-2 gap {gaps.min():.4f}")
-    rec = {}
-    with torch.no_grad():
-        otoks = O.generate_batch(sd, lmp, prefix, N_STEPS, 0.8, 1.0, 0, record=rec).numpy()
-    assert np.array_equal(otoks, toks), (otoks, toks)
-    d = maxdiff(torch.stack(rec["logits"]), L)
-    print(f"oracle logits vs reference: {d[0]:.3e} abs")
-    assert d[0] < 2e-3
-
-    # EOS semantics: stop id := token row 0 produced at step 3 -> B=1 run must break right after it
-    stop = int(toks[0, 3])
-    with torch.no_grad():
-        s_eos, t_eos, _ = ref_generate_tokens(model, prefix[:1], N_STEPS, stop_id=stop)
-        s_eos2, t_eos2, _ = ref_generate_tokens(model, prefix, N_STEPS, stop_id=stop)
-    print("eos case:", stop, t_eos, [len(t) for t in t_eos2])
-    np.savez_compressed(
-        os.path.join(args.out, "gen.npz"),
-        seed=SEED, B=B, steps=N_STEPS, tokens=toks, logits_sub=L[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB,
-        logits_step0=L[0].numpy(), top2_gap=gaps,
-        eos_stop_id=stop, eos_b1_tokens=np.asarray(t_eos[0], dtype=np.int64),
-        eos_b2_len=np.asarray([len(t) for t in t_eos2], dtype=np.int64),
-        eos_b2_row0=np.asarray(t_eos2[0], dtype=np.int64), eos_b2_row1=np.asarray(t_eos2[1], dtype=np.int64),
-    )
-
-    # ------------------------------------------------------------------ case "long30": 30 s -> 7 crops
-    if not args.skip_long:
-        a30 = torch.from_numpy(synth.make_clip(900, 960000))[None]
-        with torch.no_grad():
-            proj_ref, _, od = model.audio_encoder(a30)
-            ot = {}
-            proj_or = O.audio_encoder(sd, a30, ot)
-        d = maxdiff(proj_or, proj_ref)
-        print(f"long30: crops={ot.get('n_crops')} oracle vs reference projected {d[0]:.3e}")
-        assert ot["n_crops"] == 7 and d[1] < 1e-4
-        fw = od["framewise_output"]
-        np.savez_compressed(
-            os.path.join(args.out, "long30.npz"),
-            clip_idx=900, n_samples=960000, n_crops=7,
-            latent=od["latent_output"].numpy(), framewise32=fw[:, 0::32, :].numpy(),
-            audio_ds=O.downsample(proj_ref).numpy(),
-        )
+    if want("gen"):
+        gen_case(args, model, sd, lmp, prefix, B, t0)
+    if want("long30") and not args.skip_long:
+        long30_case(args, model, sd)
+    if want("late"):
+        late_case(args, model, prefix, t0)
+    if want("ragged") or want("eos"):
+        ragged_eos_cases(args, model, sd, lmp, t0, want)
     print(f"done ({time.time() - t0:.1f}s)")
 
 

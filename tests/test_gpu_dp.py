@@ -1,0 +1,112 @@
+"""GPU (-m gpu): the data-parallel path with REAL engines (BASELINE configs[2]): one process per rank, every
+rank with its own engine + weight replica, contiguous shards, ONE gather of the token ids at the end.
+
+The GPU box has one MI355X, so the two ranks share device 0 and rendezvous over gloo (the collective's buffers live on the
+host); on an 8-GPU node the same code runs one rank per GPU over RCCL (backend "nccl").  What is exercised here is
+everything except the transport: sharding, per-rank engines, ragged/empty shards, early-stopping shards, gather order."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+golden = os.path.join(sys.argv[1], "tests", "golden")
+from mellow_amd import dist as mdist, synth
+from mellow_amd.engine import Engine
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+sd = synth.make_state_dict(0)
+eng = Engine(device=0)
+eng.load_state_dict(sd)
+
+# (1) fixed-length, B = 5 over 2 ranks (shards 3 + 2): gathered == the same examples in ONE process, and rows 0-1 == goldens
+B, L = 5, 8
+a1, a2, ids = synth.make_batch(B)
+toks, lens = mdist.generate_sharded(eng.generate, a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
+want, *_ = eng.generate(a1, a2, ids, max_len=L, stop_id=0, ignore_stop=True)
+assert toks.shape == (B, L) and np.array_equal(toks, want), (rank, toks, want)
+g = np.load(os.path.join(golden, "gen.npz"))
+assert np.array_equal(toks[:2], g["tokens"][:, :L])
+
+# (2) reference stop rule per shard: rows (1, 2 | 4) with the mixed-EOS golden's stop id -> rank 0 stops after step 17,
+#     rank 1 after step 3; the gathered texts are the reference's
+e = np.load(os.path.join(golden, "eos_mixed.npz"))
+rows = e["all_stop_examples"].tolist()
+a1, a2, ids = synth.make_examples(rows)
+toks, lens = mdist.generate_sharded(eng.generate, a1, a2, ids, max_len=int(e["max_len"]), stop_id=int(e["stop_id"]))
+assert lens.tolist() == e["all_stop_len"].tolist(), (rank, lens)
+for r in range(len(rows)):
+    assert toks[r, : lens[r]].tolist() == e[f"all_stop_row{r}"].tolist()
+
+# (3) more ranks than examples: rank 1 gets an empty shard and still takes part in the gather
+a1, a2, ids = synth.make_batch(1)
+toks, lens = mdist.generate_sharded(eng.generate, a1, a2, ids, max_len=4, stop_id=0, ignore_stop=True)
+assert np.array_equal(toks, g["tokens"][:1, :4])
+
+# (4) the public API: MellowWrapper.generate shards by itself under an initialised process group
+from mellow_amd import MellowWrapper
+class Tok:
+    def encode(self, s): return [0] if s == "<|endoftext|>" else [17 + (sum(s.encode()) * 7919 + i * 104729) % 49000 for i, _ in enumerate(s.split())]
+    def encode_plus(self, text, max_length=129, **kw):
+        ids = self.encode(text)[:max_length]
+        return {"input_ids": torch.tensor([ids + [1] * (max_length - len(ids))]), "attention_mask": torch.tensor([[1] * max_length])}
+    def decode(self, ids): return " ".join("<|endoftext|>" if int(i) == 0 else f"t{int(i)}" for i in ids)
+import wave
+def wav(path, f, secs, sr):
+    t = np.arange(int(secs * sr)) / sr
+    pcm = (0.3 * np.sin(2 * np.pi * f * t) * 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+tmp = sys.argv[2]
+paths = []
+for i, (f, secs, sr) in enumerate(((440, 2.5, 44100), (1000, 10.0, 32000), (250, 4.0, 48000))):
+    p = os.path.join(tmp, f"r{rank}_{i}.wav")       # every rank writes the same content under its own name
+    wav(p, f, secs, sr)
+    paths.append(p)
+examples = [[paths[0], paths[1], "compare the two"], [paths[1], paths[2], "which is higher"], [paths[2], paths[0], "describe"]]
+m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok())
+sharded = m.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)
+m1 = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=False)
+alone = m1.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)
+assert len(sharded) == 3 and sharded == alone, (rank, sharded, alone)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _torchrun(args, port, extra_env=None, timeout=1500):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="8",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_two_ranks_real_engines_shard_and_gather(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_WORKER)
+    r = _torchrun([str(script), ROOT, str(tmp_path)], 29741)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_bench_two_ranks_prints_one_line_with_n_gpus_2():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) with both ranks on GPU 0 over gloo."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"], 29743,
+                  {"MELLOW_BENCH_BACKEND": "gloo", "MELLOW_BENCH_DEVICE": "0"})
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"

@@ -157,3 +157,55 @@ def test_bench_cli_contract_flags():
     assert r.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--precision", "--inflight", "--no-cpu-baseline"):
         assert flag in r.stdout
+
+
+def test_reference_import_name_is_a_drop_in():
+    """`from mellow import MellowWrapper` (reference mellow/__init__.py:1, README.md:47) resolves to this build's wrapper."""
+    import importlib
+    sys.modules.pop("mellow", None)
+    sys.path.insert(0, ROOT)
+    try:
+        m = importlib.import_module("mellow")
+        from mellow_amd.wrapper import MellowWrapper as W
+        assert m.MellowWrapper is W
+        assert importlib.import_module("mellow.wrapper").MellowWrapper is W
+        assert os.path.dirname(m.__file__) == os.path.join(ROOT, "mellow")
+    finally:
+        sys.path.remove(ROOT)
+
+
+def test_resampler_closed_form_properties():
+    """PARITY UNPINNED against torchaudio (absent offline).  What any sinc-Hann resampler with torchaudio's defaults must
+    satisfy: output length ceil(new*n/orig) (the reference's fixtures: 403,604 @ 44.1 kHz -> 292,865), DC gain 1, an in-band
+    tone keeps amplitude/frequency, a tone above the new Nyquist is rejected."""
+    for sr, n, want in ((44100, 403604, 292865), (44100, 441, 320), (48000, 3, 2), (16000, 5, 10), (22050, 1, 2)):
+        assert audio.resample(torch.zeros(1, n), sr, 32000).shape == (1, want), (sr, n)
+    sr, n = 44100, 44100
+    dc = audio.resample(torch.full((1, n), 0.5), sr, 32000)[0]
+    assert float((dc[200:-200] - 0.5).abs().max()) < 1e-3      # a width-6 windowed sinc has ~5e-4 DC ripple
+    t = np.arange(n) / sr
+    # the width-6 window gives a wide transition band: 1 kHz passes to 2e-4, 12 kHz loses 1.5 %, the cut-off (0.99 x 16 kHz)
+    # is the half-amplitude point, 20 kHz (aliasing to 12 kHz if it leaked) is down to 0.7 %
+    for f, tol in ((1000.0, 1e-3), (12000.0, 3e-2)):
+        y = audio.resample(torch.from_numpy(np.sin(2 * np.pi * f * t).astype(np.float32))[None], sr, 32000)[0].numpy()
+        ref = np.sin(2 * np.pi * f * np.arange(len(y)) / 32000.0)
+        assert np.abs(y[500:-500] - ref[500:-500]).max() < tol, f
+    y = audio.resample(torch.from_numpy(np.sin(2 * np.pi * 15900.0 * t).astype(np.float32))[None], sr, 32000)[0].numpy()
+    assert 0.35 < np.abs(y[500:-500]).max() < 0.65
+    y = audio.resample(torch.from_numpy(np.sin(2 * np.pi * 20000.0 * t).astype(np.float32))[None], sr, 32000)[0].numpy()
+    assert np.abs(y[500:-500]).max() < 1e-2
+
+
+def test_non_finite_samples_are_sanitised_and_formats_reported(tmp_path):
+    from scipy.io import wavfile
+    x = np.zeros(2000, dtype=np.float32)
+    x[10], x[20], x[30] = np.nan, np.inf, -np.inf
+    p = str(tmp_path / "f32.wav")
+    wavfile.write(p, 32000, x)
+    with pytest.warns(UserWarning, match="non-finite"):
+        w, sr = audio.load_wav(p)
+    assert sr == 32000 and torch.isfinite(w).all() and float(w[0, 20]) == 1.0 and float(w[0, 30]) == -1.0 and float(w[0, 10]) == 0.0
+    bad = tmp_path / "clip.mp3"
+    bad.write_bytes(b"ID3\x03\x00\x00\x00\x00\x00\x00not really audio")
+    with pytest.raises(ValueError, match="cannot decode audio.*PCM / float WAV"):
+        audio.load_wav(str(bad))

@@ -7,7 +7,11 @@ tools/pmc_prefill.py) into the per-launch memory-side traffic of the gemm_f32_ke
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16  # noqa: E402  (bench.py refuses to print a result measured on other kernel sources)
 
 
 def family(path, counter):
@@ -26,6 +30,7 @@ out = {
     "kernel": "gemm_f32_kernel (all instances)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py "
               "(2 encoder+prefill passes at B=32); reduced with tools/pmc_traffic.py",
+    "source_sha16": kernel_source_sha16(),
     "launches": nf,
     "fetch_size_kb_per_launch": fetch / nf,
     "write_size_kb_per_launch": write / nw,
