@@ -244,6 +244,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             const int gi = g0 + u * DA_WAVES;
             const int t = gi * 4 + sub;
             const bool ok = gi < gend && t < pos;
+            // a slot beyond the context may hold anything (an earlier call's pages, even NaN from a poisoned request):
+            // its weight is exp(-inf) = 0, but 0 x NaN is NaN, so the value itself is cleared too
+            if (!ok) v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) {
                 float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;

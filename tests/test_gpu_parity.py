@@ -343,6 +343,10 @@ def test_stop_at_first_token_and_nan_audio(engine, batch2, golden_dir):
     toks, lens, n, _ = engine.generate(bad, a2, ids, max_len=4, stop_id=-1)
     assert toks[0].tolist() == [0, 0, 0, 0]
     assert toks[1].tolist() == g["tokens"][1, :4].tolist()
+    # ... and the poisoned request leaves nothing behind: the NaN K/V it appended beyond the next call's context are
+    # masked by value, not only by weight
+    toks, *_ = engine.generate(a1, a2, ids, max_len=4, stop_id=-1)
+    assert np.array_equal(toks, g["tokens"][:, :4])
     with pytest.raises(IndexError):
         engine.generate(a1, a2, np.full_like(ids, 49152), max_len=2)
 
