@@ -114,7 +114,11 @@ def cpu_baseline(max_len: int):
     tried = {str(base): round(time.time() - t0, 3)}
     _progress(f"cpu_baseline: 3-step trial with {base} threads: {tried[str(base)]} s")
     threads = base
-    if usable > base:
+    if quota is not None and quota <= base:
+        # the container is capped at `quota` CPUs: more threads than that only time-slice (measured once on this pool: the
+        # 256-thread trial did not finish in 55 s against 0.5 s with 16 threads -- profiles/r02_bench.json of commit 5d0c0ce..)
+        tried[str(usable)] = f"not tried: cgroup cpu.max caps the container at {quota} CPUs"
+    elif usable > base:
         import subprocess
         code = ("import sys, time, torch; sys.path.insert(0, %r); import bench; from mellow_amd import synth; "
                 "from oracle import mellow_oracle as O; torch.set_num_threads(%d); sd = synth.make_state_dict(0); "

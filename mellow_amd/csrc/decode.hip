@@ -40,6 +40,13 @@ void set_kernel_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 // softmax weights: exp(x) = 2^(x*log2 e) on the hardware v_exp_f32 (x <= 0 here; ~1e-6 relative, far inside the fp32
 // summation-order noise of a 64..700-key softmax); exp(-inf) = 0 exactly
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// streamed-once operands (weights, KV pages): non-temporal loads (`global_load_dwordx4 ... nt`).  Each of these lines is read
+// by exactly one workgroup per step, so keeping it in L2 buys nothing, and the nt policy shortens issue -> landed by ~18 %
+// on this part (MI355X_MICROARCH.md, row nt-weights)
+__device__ __forceinline__ float4 ldg_nt(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
         float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-            w[i] = wp[i * 64];
+            w[i] = ldg_nt(wp + i * 64);
             x[i] = xb[i * 64];
 #pragma unroll
             for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     for (int u = 0; u < DA_G; ++u) {
         const int gi = gbeg + wave + u * DA_WAVES;
         const int tc = min(gi * 4 + sub, Tmax - 1);               // inside the page; validity is decided later
-        k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
-        v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
+        k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
+        v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
     }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 1, dbg);
@@ -232,8 +239,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             for (int u = 0; u < DA_G; ++u) {
                 const int gi = g0 + u * DA_WAVES;
                 const int tc = min(gi * 4 + sub, Tmax - 1);
-                k4[u] = *reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4);
-                v4[u] = *reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4);
+                k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
+                v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -244,9 +251,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             const int gi = g0 + u * DA_WAVES;
             const int t = gi * 4 + sub;
             const bool ok = gi < gend && t < pos;
-            // a slot beyond the context may hold anything (an earlier call's pages, even NaN from a poisoned request):
-            // its weight is exp(-inf) = 0, but 0 x NaN is NaN, so the value itself is cleared too
-            if (!ok) v4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // masked by weight (exp(-inf) = 0): slots beyond the context hold finite values (engine.cpp clear_page_tails)
 #pragma unroll
             for (int hh = 0; hh < 3; ++hh) {
                 float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = wave + 16 * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
-        w[i] = wp[(int64_t)tc * 64];
+        w[i] = ldg_nt(wp + (int64_t)tc * 64);
         if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
     const int dslot = 5;
     kstamp(dslot, 0, dbg);
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) { w[i] = wp[i * 64]; x[i] = xp[i * 64]; }
+    for (int i = 0; i < KPW; ++i) { w[i] = ldg_nt(wp + i * 64); x[i] = xp[i * 64]; }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(dslot, 1, dbg);
     f32x16 acc;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
     float4 w[TPW], x0[TPW], x1[TPW], s4[9];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        w[i] = wp[i * 64];
+        w[i] = ldg_nt(wp + i * 64);
         x0[i] = xp[(i * 2) * 64];
         x1[i] = xp[(i * 2 + 1) * 64];
     }
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
     float4 w[KPW], h4[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        w[i] = wp[i * 64];
+        w[i] = ldg_nt(wp + i * 64);
         h4[i] = hp[i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);

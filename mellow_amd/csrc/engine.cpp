@@ -971,7 +971,8 @@ static int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samp
 static inline int rb_of(int B) { return (B + 31) / 32; }
 static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
 
-static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
+static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) {
+    if (ctx_end <= 0 || ctx_end > Tmax) ctx_end = Tmax;      // last context length the call will reach (<= page capacity)
     if (Tmax > 2048) return fail("prefix + max_len = %d exceeds the 2048-key decode attention limit", Tmax);
     if (Tmax > e->cfg.max_positions) return fail("prefix + max_len = %d exceeds max_positions %d", Tmax, e->cfg.max_positions);
     const size_t Mp = (size_t)B * T;
@@ -1024,15 +1025,34 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax) {
         {
             // key split of the decode attention: balanced at the END of the reserved context, rounded down to whole
             // passes of a workgroup when that costs at most 4 groups of imbalance
-            const int ng_end = (Tmax - 1 + 3) / 4, chunk = dec_attn_chunk_groups();
+            const int ng_end = (ctx_end - 1 + 3) / 4, chunk = dec_attn_chunk_groups();
             int gs = (ng_end + DEC_TS - 1) / DEC_TS;
             if (gs > chunk && gs % chunk <= 4) gs -= gs % chunk;
-            a.gs = gs < 1 ? 1 : gs;
+            gs = gs < 1 ? 1 : gs;
+            if (gs != a.gs) {     // the split is baked into captured launches
+                if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
+                if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
+            }
+            a.gs = gs;
         }
         a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu; a.xmidF16 = p + o_xmidF16;
         a.logits = e->dlogits.p; a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * (V / 32));
     }
     if (Bp > 1024) return fail("batch too large for the decode state block");
+    return 0;
+}
+
+// The decode attention loads whole key groups before it knows the position and masks them by WEIGHT (exp(-inf) = 0): a
+// slot beyond the context must therefore hold a finite value, or 0 x NaN poisons the row.  A fresh page is zeroed when it
+// is allocated; a reused one may hold an earlier call's appended keys -- even NaN from a poisoned request -- so the V slots
+// [T, Tmax) of every page are cleared once per prefill (one strided memset, ~0.1 GB at B = 32; K needs none: a NaN score of
+// a masked key is replaced by -inf with a select).
+static int clear_page_tails(mellow_engine* e, int T) {
+    const int Tmax = e->kv_Tmax;
+    if (T >= Tmax) return 0;
+    const size_t pitch = (size_t)Tmax * 64 * sizeof(float), width = (size_t)(Tmax - T) * 64 * sizeof(float);
+    const size_t pages = (size_t)e->cfg.num_layers * e->kv_B * 3;
+    HIPCHK(hipMemset2DAsync(e->vcache.p + (size_t)T * 64, pitch, 0, width, pages, e->stream));
     return 0;
 }
 
@@ -1226,6 +1246,7 @@ int mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int
     HIPCHK(hipSetDevice(e->device));
     CHK(ensure_lm(e, B, T, T + reserve + 1));
     HIPCHK(hipMemcpyAsync(e->lm_x.p, prefix, (size_t)B * T * 576 * 4, hipMemcpyDeviceToDevice, e->stream));
+    CHK(clear_page_tails(e, T));
     CHK(run_prefill(e, B, T, nullptr));
     if (logits)
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1350,7 +1371,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // KV page geometry in buckets of 64 positions, so that nearby max_len values share pages, key split and graphs
     int Tmax = rup(T + max_len, 64);
     if (Tmax > e->cfg.max_positions || Tmax > 2048) Tmax = T + max_len;
-    CHK(ensure_lm(e, B, T, Tmax));
+    CHK(ensure_lm(e, B, T, Tmax, T + max_len));
     const int Bp = e->da.rows;
     CHK(ensure(e, e->out_tok, (size_t)Bp * max_len));
     HIPCHK(hipEventRecord(e->ev_phase[0], s));
@@ -1361,6 +1382,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     e->h_params[0] = max_len;
     e->h_params[1] = stop_id;
     HIPCHK(hipMemcpyAsync(e->d_params, e->h_params, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CHK(clear_page_tails(e, T));
     CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
     HIPCHK(hipEventRecord(e->ev_phase[1], s));
     RecordArgs rec;
