@@ -60,12 +60,12 @@ class MellowWrapper:
 
     def __init__(self, config, model, device, use_cuda=True, *, checkpoint: Optional[str] = None,
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: int = 2048,
-                 data_parallel: Optional[bool] = None):
+                 data_parallel: Optional[bool] = None, precision: Optional[str] = None):
         """Reference signature `MellowWrapper(config, model, device, use_cuda=True)` (wrapper.py:35) plus keyword-only
         extensions: `checkpoint` (a local .ckpt instead of the hub download), `state_dict` (already loaded), `tokenizer`
         (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; the decode
         attention supports 2048 keys), `data_parallel` (None: shard `generate` over the ranks of an initialised
-        torch.distributed group, one process per GPU; False: never)."""
+        torch.distributed group, one process per GPU; False: never), `precision` ("f32" | "f32x3" | "fp8")."""
         self.supported_versions = self.model_name.keys()
         if model not in self.supported_versions:
             raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
@@ -78,6 +78,9 @@ class MellowWrapper:
         self._tokenizer_override = tokenizer
         self._max_positions = max_positions
         self._data_parallel = data_parallel
+        # numeric mode of the dense GEMMs (include/mellow_hip.h): "f32" exact fp32 MFMA (default), "f32x3" fp32-accurate
+        # bf16-split, "fp8" BASELINE config 5; keyword or MELLOW_PRECISION
+        self._precision = precision or os.environ.get("MELLOW_PRECISION", "f32")
         self.model, self.tokenizer, self.args = self.get_model_and_tokenizer(config_path=self.config_path)
 
     # ---- construction -------------------------------------------------------------------------------------
@@ -120,7 +123,7 @@ class MellowWrapper:
         if not self.use_cuda or isinstance(self.device, str):
             raise RuntimeError("MellowWrapper (MI355X engine) has no CPU path: pass use_cuda=True and an integer device")
         lm = LMConfig.load()
-        engine = Engine(lm=lm, device=int(self.device), max_positions=self._max_positions)
+        engine = Engine(lm=lm, device=int(self.device), max_positions=self._max_positions, precision=self._precision)
         sd = self._state_dict
         if sd is None:
             sd = torch.load(self.model_path, map_location=torch.device("cpu"))

@@ -26,10 +26,23 @@ def _close(got, ref, rel=2e-4, atol=0.0, name=""):
     assert d <= lim, f"{name}: max|d| {d:.3e} > {lim:.3e}"
 
 
-@pytest.fixture(scope="module")
-def engine(synth_sd):
+# Every test that takes `engine` runs twice: on the exact fp32 MFMA path ("f32") and on the fp32-accurate bf16-split path
+# ("f32x3": each fp32 operand is the exact sum of three bf16 terms, six bf16 MFMA products per fp32 product, fp32
+# accumulation -- DESIGN.md 6c).  Both are held to the SAME tolerances and to exact token equality with the reference goldens.
+@pytest.fixture(scope="module", params=["f32", "f32x3"])
+def engine(request, synth_sd):
     from mellow_amd.engine import Engine
-    e = Engine(device=0, max_positions=1024)          # raises (does not fall back) without GPU / library
+    e = Engine(device=0, precision=request.param)      # raises (does not fall back) without GPU / library
+    e.load_state_dict(synth_sd)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def engine_f32(synth_sd):
+    """the exact-fp32 engine, for tests that compare another mode against it or are precision-independent"""
+    from mellow_amd.engine import Engine
+    e = Engine(device=0)
     e.load_state_dict(synth_sd)
     yield e
     e.close()
@@ -51,11 +64,11 @@ def oracle_taps(synth_sd, batch2):
     return prefix, taps
 
 
-def test_native_library_is_loaded(engine):
+def test_native_library_is_loaded(engine_f32):
     """the product path IS the HIP library: it must be mapped into this process"""
     maps = open("/proc/self/maps").read()
     assert "libmellow_hip.so" in maps
-    assert engine.lib.mellow_device_count() >= 1
+    assert engine_f32.lib.mellow_device_count() >= 1
 
 
 def test_frontend_logmel(engine, batch2, oracle_taps, golden_dir):
@@ -469,7 +482,7 @@ def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
     assert np.array_equal(t[0, :4], np.asarray(want)[0])
 
 
-def test_pipelined_contexts_give_identical_tokens(engine, synth_sd):
+def test_pipelined_contexts_give_identical_tokens(engine_f32, synth_sd):
     """mellow_amd.serve.EnginePool: two contexts on one GPU, batches in flight concurrently == one engine, batch by batch."""
     from mellow_amd.serve import EnginePool
     pool = EnginePool(synth_sd, n_contexts=2, device=0)
@@ -477,7 +490,7 @@ def test_pipelined_contexts_give_identical_tokens(engine, synth_sd):
     got = pool.generate_many(batches, max_len=6, stop_id=0, ignore_stop=True)
     pool.close()
     for (a1, a2, ids), res in zip(batches, got):
-        want, *_ = engine.generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
+        want, *_ = engine_f32.generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
         assert np.array_equal(res[0], want)
 
 
@@ -489,7 +502,7 @@ def _quant_rows_e4m3(x):
     return (x * inv).to(torch.float8_e4m3fn).to(torch.float32), scale
 
 
-def test_fp8_gemm_matches_quantised_emulation(engine):
+def test_fp8_gemm_matches_quantised_emulation(engine_f32):
     """The fp8 GEMM == exact products of the SAME e4m3 operands (per-row scales, RNE) accumulated in fp32.
     Tolerance: fp32 accumulation-order noise (1e-4 of max) plus the rare element whose scaled value sits on a rounding
     tie and lands one e4m3 step apart (bounded by 2e-3 of max); the quantisation itself costs ~4e-2 vs the exact product."""
@@ -498,7 +511,7 @@ def test_fp8_gemm_matches_quantised_emulation(engine):
         A = torch.randn(M, K) * (0.2 + 3 * torch.rand(M, 1))
         W = torch.randn(N, K) * 0.05 * (1 + torch.rand(N, 1))
         A[3] = 0.0                                                     # an all-zero row must quantise to zeros
-        got, _ = engine.debug_gemm_fp8(A, W)
+        got, _ = engine_f32.debug_gemm_fp8(A, W)
         Aq, sa = _quant_rows_e4m3(A)
         Wq, sw = _quant_rows_e4m3(W)
         ref = (Aq.double() @ Wq.double().T) * sa.double() * sw.double().T
@@ -512,28 +525,28 @@ def test_fp8_gemm_matches_quantised_emulation(engine):
         assert float((ref - exact).abs().max()) > 5e-3 * scale            # sanity: the emulation really is quantised
 
 
-def test_fp8_mode_end_to_end(synth_sd, engine, golden_dir):
+def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     """precision="fp8": e4m3 GEMMs in the Swin linears and LM prefill, everything else fp32.  Not bit-exact by design;
     the test pins (a) determinism, (b) bounded error against the fp32 engine, (c) that the fp32 engine is untouched.
     Measured on the synthetic (random-weight, un-trained) checkpoint: prefix rel-rms 5e-2, prefill logits rel-rms 0.17,
     first-token agreement ~0.6 -- a random network amplifies 3-bit-mantissa noise; see DESIGN.md §9."""
     from mellow_amd.engine import Engine
-    e8 = Engine(device=0, max_positions=1024, precision="fp8")
+    e8 = Engine(device=0, precision="fp8")
     e8.load_state_dict(synth_sd)
     B = 16
     a1, a2, ids = synth.make_batch(B)
-    p32 = engine.prefix(a1, a2, ids)
+    p32 = engine_f32.prefix(a1, a2, ids)
     p8 = e8.prefix(a1, a2, ids)
     rel = float((p8 - p32).pow(2).mean().sqrt() / p32.pow(2).mean().sqrt())
     assert torch.isfinite(p8).all() and 1e-4 < rel < 0.15, rel
-    l32 = engine.lm_prefill(p32, reserve=2).cpu()
+    l32 = engine_f32.lm_prefill(p32, reserve=2).cpu()
     l8 = e8.lm_prefill(p32, reserve=2).cpu()
     rel_l = float((l8 - l32).pow(2).mean().sqrt() / l32.pow(2).mean().sqrt())
     assert torch.isfinite(l8).all() and rel_l < 0.5, rel_l
     t8a, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     t8b, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     assert np.array_equal(t8a, t8b)                                      # deterministic
-    t32, *_ = engine.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
+    t32, *_ = engine_f32.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     agree = float((t8a[:, 0] == t32[:, 0]).mean())
     assert agree >= 0.25, agree                                          # far above chance (1/49152)
     g = np.load(os.path.join(golden_dir, "gen.npz"))
@@ -547,7 +560,7 @@ def test_fp8_mode_end_to_end(synth_sd, engine, golden_dir):
     e8.close()
 
 
-def test_f32x3_mode_is_fp32_accurate(engine, synth_sd, golden_dir):
+def test_f32x3_mode_is_fp32_accurate(engine_f32, synth_sd, golden_dir):
     """Experimental precision="f32x3": fp32 GEMMs run as exact 3-way bf16 operand splits on the bf16 MFMA pipe.
     (a) one GEMM against an fp64 product: no less accurate than the exact fp32 MFMA kernel (x1.25 slack on max / rms);
     (b) end to end: greedy tokens identical to the fp32 engine and to the reference goldens, logits within the same
@@ -557,21 +570,21 @@ def test_f32x3_mode_is_fp32_accurate(engine, synth_sd, golden_dir):
     A = torch.randn(389, 576) * (0.2 + 3 * torch.rand(389, 1))
     W = torch.randn(576, 576) * 0.05
     exact = A.double() @ W.double().T
-    e_mfma = (engine.debug_gemm_f32(A, W, mode=0)[0].double() - exact).abs()
+    e_mfma = (engine_f32.debug_gemm_f32(A, W, mode=0)[0].double() - exact).abs()
     for mode in (6, 9, 16):
-        e_x3 = (engine.debug_gemm_f32(A, W, mode=mode)[0].double() - exact).abs()
+        e_x3 = (engine_f32.debug_gemm_f32(A, W, mode=mode)[0].double() - exact).abs()
         assert float(e_x3.max()) <= 1.25 * float(e_mfma.max()) and float(e_x3.pow(2).mean()) <= 1.25 ** 2 * float(e_mfma.pow(2).mean())
-    e3 = Engine(device=0, max_positions=1024, precision="f32x3")
+    e3 = Engine(device=0, precision="f32x3")
     e3.load_state_dict(synth_sd)
     a1, a2, ids = synth.make_batch(4)
     t3, *_ = e3.generate(a1, a2, ids, max_len=12, stop_id=0, ignore_stop=True)
-    t0, *_ = engine.generate(a1, a2, ids, max_len=12, stop_id=0, ignore_stop=True)
+    t0, *_ = engine_f32.generate(a1, a2, ids, max_len=12, stop_id=0, ignore_stop=True)
     assert np.array_equal(t3, t0)
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t3[:2], g["tokens"])
     e = np.load(os.path.join(golden_dir, "enc10.npz"))
     prefix = torch.from_numpy(e["prefix"])
-    _close(e3.lm_prefill(prefix, reserve=2), engine.lm_prefill(prefix, reserve=2), rel=0, atol=3e-3, name="f32x3 prefill logits")
+    _close(e3.lm_prefill(prefix, reserve=2), engine_f32.lm_prefill(prefix, reserve=2), rel=0, atol=3e-3, name="f32x3 prefill logits")
     e3.close()
 
 
@@ -609,7 +622,7 @@ def test_encoder_activations_beyond_4gib(engine):
         assert torch.equal(big[idx], alone[0]), idx
 
 
-def test_device_resampler_matches_host_twin_parity_unpinned(engine):
+def test_device_resampler_matches_host_twin_parity_unpinned(engine_f32):
     """PARITY UNPINNED against torchaudio (absent offline): mellow_resample (A0 on the device) == mellow_amd.audio.resample
     (the host restatement of torchaudio's sinc_interp_hann defaults): 44.1 kHz -> 32 kHz and 48 kHz -> 32 kHz, odd lengths,
     two clips at once.  Tolerance: fp32 summation order of a 459-tap dot product.  The closed-form properties of the filter
@@ -619,19 +632,19 @@ def test_device_resampler_matches_host_twin_parity_unpinned(engine):
     for sr, n in ((44100, 403604), (48000, 12345), (16000, 4000), (22050, 1)):
         x = torch.from_numpy((rng.standard_normal((2, n)) * 0.3).astype(np.float32))
         want = audio.resample(x, sr, 32000)
-        got = engine.resample(x, sr, 32000).cpu()
+        got = engine_f32.resample(x, sr, 32000).cpu()
         assert got.shape == want.shape, (sr, n, got.shape, want.shape)
         assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (sr, n)
 
 
-def test_device_resampler_closed_form(engine):
+def test_device_resampler_closed_form(engine_f32):
     """Properties any sinc-Hann resampler with torchaudio's defaults (width 6, rolloff 0.99) must have, independent of the
     host twin: output length ceil(new*n/orig) for the reference's own fixture lengths (resource/1.wav: 403,604 @ 44.1 kHz ->
     292,865), DC gain 1, an in-band tone keeps amplitude and frequency, a tone above the new Nyquist is rejected."""
     for sr, n, want in ((44100, 403604, 292865), (44100, 441, 320), (48000, 3, 2), (16000, 5, 10)):
-        assert engine.resample(torch.zeros(1, n), sr, 32000).shape == (1, want), (sr, n)
+        assert engine_f32.resample(torch.zeros(1, n), sr, 32000).shape == (1, want), (sr, n)
     sr, n = 44100, 44100
-    dc = engine.resample(torch.full((1, n), 0.5), sr, 32000).cpu()[0]
+    dc = engine_f32.resample(torch.full((1, n), 0.5), sr, 32000).cpu()[0]
     assert float((dc[200:-200] - 0.5).abs().max()) < 1e-3      # a width-6 windowed sinc has ~5e-4 DC ripple
     t = np.arange(n) / sr
     # the width-6 window gives a wide transition band: 1 kHz passes to 2e-4, 12 kHz loses 1.5 %, the cut-off (0.99 x 16 kHz)
@@ -639,7 +652,7 @@ def test_device_resampler_closed_form(engine):
     for f, lo, hi, tol in ((1000.0, None, None, 1e-3), (12000.0, None, None, 3e-2), (15900.0, 0.35, 0.65, None),
                            (20000.0, 0.0, 1e-2, None)):
         x = torch.from_numpy(np.sin(2 * np.pi * f * t).astype(np.float32))[None]
-        y = engine.resample(x, sr, 32000).cpu()[0].numpy()
+        y = engine_f32.resample(x, sr, 32000).cpu()[0].numpy()
         mid = y[500:-500]
         if tol is not None:
             ref = np.sin(2 * np.pi * f * np.arange(len(y)) / 32000.0)[500:-500]
