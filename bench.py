@@ -153,11 +153,11 @@ def cpu_baseline(max_len: int):
     }
 
 
-def north_star_b64(L: int):
+def north_star_b64(L: int, precision: str):
     """The north_star's stated batch (64 examples per GPU, 2x10 s clips, max_len 64) on this GPU: 2 timed passes."""
     from mellow_amd import synth
     from mellow_amd.engine import Engine
-    e = Engine(device=0)
+    e = Engine(device=0, precision=precision)
     e.load_state_dict(synth.make_state_dict(0))
     a1, a2, ids = synth.make_batch(64)
     a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
@@ -170,22 +170,31 @@ def north_star_b64(L: int):
     dt = (time.perf_counter() - t0) / 2
     ph = e.last_phase_ms()
     e.close()
-    t_roof = 64 * (DENSE_GFLOP_PER_RESPONSE / (PEAK_F32_MFMA_TFLOPS * 1e3)) + decode_algorithmic_bytes(64, L) / (PEAK_HBM_GBS * 1e9)
+    peak = PEAK_F32X3_TFLOPS if precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+    t_roof = 64 * (DENSE_GFLOP_PER_RESPONSE / (peak * 1e3)) + decode_algorithmic_bytes(64, L) / (PEAK_HBM_GBS * 1e9)
     return {"batch": 64, "value": round(64 / dt, 2), "unit": "responses/s", "ms_per_pass": round(dt * 1e3, 2),
             "first_token_ms": round(ftm, 2), "phase_ms": {k: round(v, 2) for k, v in ph.items()},
             "decode_ms_per_step": round(ph["decode_ms"] / (L - 1), 4),
             "path_roofline_frac": round(t_roof * 1e3 / (dt * 1e3), 4)}
 
 
-def alt_modes(B: int, L: int):
-    """Supplementary, never the headline: the two opt-in numeric modes on the same workload (3 passes each)."""
+ALT_NOTES = {
+    "f32": "exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), the mode the parity suite calls 'f32'; tokens identical to f32x3",
+    "f32x3": "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)",
+    "fp8": "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill; not bit-exact (DESIGN 6b)",
+}
+
+
+def alt_modes(B: int, L: int, headline: str):
+    """Supplementary, never the headline: the other numeric modes on the same workload (3 passes each)."""
     from mellow_amd import synth
     from mellow_amd.engine import Engine
     sd = synth.make_state_dict(0)
     a1, a2, ids = synth.make_batch(B)
     res = {}
-    for prec, note in (("f32x3", "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)"),
-                       ("fp8", "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill; not bit-exact (DESIGN 6b)")):
+    for prec in ("f32", "f32x3", "fp8"):
+        if prec == headline:
+            continue
         e = Engine(device=0, precision=prec)
         e.load_state_dict(sd)
         a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
@@ -196,7 +205,8 @@ def alt_modes(B: int, L: int):
             _, _, _, ftm = e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
         torch.cuda.synchronize()
         res[prec] = {"value": round(3 * B / (time.perf_counter() - t0), 2), "unit": "responses/s",
-                     "first_token_ms": round(ftm, 2), "note": note}
+                     "first_token_ms": round(ftm, 2), "phase_ms": {k: round(v, 2) for k, v in e.last_phase_ms().items()},
+                     "note": ALT_NOTES[prec]}
         e.close()
     return res
 
@@ -231,9 +241,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="examples per GPU")
     ap.add_argument("--max-len", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("f32", "fp8", "f32x3"), default="f32",
-                    help="f32 (default, the headline: exact fp32 MFMA) or fp8 (BASELINE config 5: e4m3 GEMMs in the encoder's "
-                         "Swin linears and LM prefill; a different metric line, not comparable with the headline)")
+    ap.add_argument("--precision", choices=("f32", "fp8", "f32x3"), default="f32x3",
+                    help="f32x3 (default: fp32-accurate GEMMs as exact 3-way bf16 splits on the bf16 MFMA pipe; passes the whole "
+                         "parity suite with the f32 tolerances and exact tokens), f32 (exact fp32 MFMA) or fp8 (BASELINE config 5: "
+                         "e4m3 GEMMs in the encoder's Swin linears and LM prefill; a different metric line)")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the supplementary fp8 / f32x3 measurements")
     ap.add_argument("--no-b64", action="store_true", help="skip the supplementary batch-64 (north_star) measurement")
     ap.add_argument("--inflight", type=int, default=0,
@@ -372,13 +383,13 @@ def main():
         out = {
             "metric": "audio-pair responses/sec (v0 167M, 2x10s clips, max_len=64, greedy)" +
                       (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else "") +
-                      (" [experimental f32x3 mode: fp32 GEMMs as exact 3-way bf16 splits on the bf16 MFMA pipe]"
-                       if args.precision == "f32x3" else ""),
+                      (" [exact-fp32-MFMA mode]" if args.precision == "f32" else ""),
             "value": round(value, 2), "unit": "responses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8_e4m3 GEMMs (Swin linears + LM prefill), f32 accumulate; decode/front-end f32" if fp8 else
-                      "f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per k-step, f32 accumulate)"
-                      if args.precision == "f32x3" else "f32"),
+                      "f32 (encoder/prefill GEMM operands split EXACTLY into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
+                      "f32 accumulate: fp32-accurate, parity suite green with the f32 tolerances; STFT, mel, attention, decode "
+                      "on exact fp32 MFMA / VALU)" if args.precision == "f32x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"v0 167M, batch {B}/GPU, 2x10s 32kHz synthetic clips + 16-token prompts, max_len={L}, "
                                    f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",
@@ -386,7 +397,9 @@ def main():
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
             "roofline": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
-                                    if fp8 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),
+                                    if fp8 else "gemm_bf16x3f_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product: encoder + LM prefill "
+                                    "GEMMs; STFT / mel stay on gemm_f32_kernel); peak = 2.5 PF dense bf16 / 6" if args.precision == "f32x3"
+                                    else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),
                          "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None if args.precision != "f32" else traffic,
                          "traffic_unit": traffic_note,
@@ -412,14 +425,14 @@ def main():
             out["reference_semantics"] = ref_sem
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        if n_gpus == 1 and args.precision == "f32" and not args.no_alt_modes:
+        if n_gpus == 1 and args.precision != "fp8" and not args.no_alt_modes:
             _progress("leg: alt_modes")
-            out["alt_modes"] = alt_modes(B, L)
+            out["alt_modes"] = alt_modes(B, L, args.precision)
         if n_gpus == 1 and args.inflight > 1:
             out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
-        if n_gpus == 1 and args.precision == "f32" and not args.no_b64 and B != 64:
+        if n_gpus == 1 and args.precision != "fp8" and not args.no_b64 and B != 64:
             _progress("leg: north_star_b64")
-            out["north_star_b64"] = north_star_b64(L)
+            out["north_star_b64"] = north_star_b64(L, args.precision)
         if n_gpus == 1 and not args.no_cpu_baseline:
             _progress("leg: cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(L)

@@ -87,7 +87,9 @@ const char* mellow_engine_required_key(int i);
  * stop_id       : tokenizer.encode(stop_token)[0] (wrapper.py:208)
  * ignore_stop   : 0 = reference semantics (loop ends when every row has produced stop_id,
  *                 wrapper.py:247-249); 1 = always run max_len steps (fixed-work benchmark mode)
- * out_tokens    : dev i32 [B][max_len]; columns >= *out_steps are undefined
+ * out_tokens    : dev i32 [B][max_len]; columns >= *out_steps are undefined.  In reference-semantics mode with more than
+ *                 one 32-row block, a block whose rows have ALL produced stop_id stops being computed (per-block early
+ *                 exit): its rows hold -1 in the columns after that step (every such row's text is already cut)
  * out_len       : host i32 [B], tokens before the row's first stop_id (the text cut of wrapper.py:254)
  * out_steps     : host, number of loop iterations the reference would have run
  * first_token_ms: host wall-clock milliseconds from call entry until the first token id of every row exists

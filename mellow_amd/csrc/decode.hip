@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
         a.rope_cur[32 + tid] = sn;
         if (tid == 0 && a.inc_pos) *a.d_pos = p;
     }
+    if (a.blk_live && a.blk_live[rb] == 0) return;      // every row of this block has stopped (workgroup-uniform)
     if (wave < 3) {
         const int k8_0 = (kc * 3 + wave) * KPW;
         const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     __shared__ float snew_s[3];
 
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    if (a.blk_live && a.blk_live[b >> 5] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tmax = a.Tmax;
     float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
     constexpr int TPW = 3, K16 = 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
+    if (a.blk_live && a.blk_live[rb] == 0) return;
     const int ml = lane & 15;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + (int64_t)nt * K16 * 64 + lane;
     // epilogue operand issued up front: thread (m, nq) of the 16 x 16 tile owns 4 consecutive columns
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
     constexpr int KPW = 18;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.z;
+    if (a.blk_live && a.blk_live[rb] == 0) return;
     const int k8_0 = wave * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
     constexpr int TPW = 9, K16 = 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y;
+    if (a.blk_live && a.blk_live[rb] == 0) return;
     const int t0 = wave * TPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * K16 + t0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
     constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
+    if (a.blk_live && a.blk_live[rb] == 0) return;
     const int k8_0 = (kc * 6 + wave) * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
@@ -613,6 +619,7 @@ template <int KCD>
 __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, const float* __restrict__ norm_w) {
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.blk_live && a.blk_live[b >> 5] == 0) return;
     const int xi = tid < 144 ? tid : 0;
     const int64_t fi = f32_idx(b >> 5, 72, b & 31, xi * 4);
     float4 v = reinterpret_cast<const float4*>(a.xmidF)[fi];
@@ -644,34 +651,43 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
     __shared__ int bi[4];
     __shared__ int tok_s;
     const int b = blockIdx.x, tid = threadIdx.x;
+    // a row whose whole block has stopped computes nothing any more, but still takes part in the step's arrival count
+    const bool dead = lp.blk_live && lp.blk_live[b >> 5] == 0;      // workgroup-uniform; written by an EARLIER launch
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-        const float v = a.cand_val[(int64_t)b * n + i];
-        const int id = a.cand_idx[(int64_t)b * n + i];
-        if (arg_better(v, id, best, idx)) { best = v; idx = id; }
-    }
+    if (!dead) {
+        for (int i = tid; i < n; i += 256) {
+            const float v = a.cand_val[(int64_t)b * n + i];
+            const int id = a.cand_idx[(int64_t)b * n + i];
+            if (arg_better(v, id, best, idx)) { best = v; idx = id; }
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
+        }
+        if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
     }
-    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (arg_better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
-        idx = min(max(idx, 0), n * 32 - 1);       // always a valid row of the embedding table (n tiles x 32 ids = vocab)
-        tokens[b] = idx;
-        tok_s = idx;
+        if (!dead) {
+            for (int w = 1; w < 4; ++w)
+                if (arg_better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
+            idx = min(max(idx, 0), n * 32 - 1);       // always a valid row of the embedding table (n tiles x 32 ids = vocab)
+            tokens[b] = idx;
+            tok_s = idx;
+        }
         if (lp.out_tokens) {
-            const int max_len = lp.params[0], stop_id = lp.params[1];
-            const int step = *a.d_pos - lp.T0 + 1;
-            if (step >= 0 && step < max_len) lp.out_tokens[(int64_t)b * max_len + step] = idx;
-            if (idx == stop_id && lp.seen_stop[b] == 0) {
-                lp.seen_stop[b] = 1;
-                atomicAdd(lp.n_seen, 1);
+            if (!dead) {
+                const int max_len = lp.params[0], stop_id = lp.params[1];
+                const int step = *a.d_pos - lp.T0 + 1;
+                if (step >= 0 && step < max_len) lp.out_tokens[(int64_t)b * max_len + step] = idx;
+                if (idx == stop_id && lp.seen_stop[b] == 0) {
+                    lp.seen_stop[b] = 1;
+                    atomicAdd(lp.n_seen, 1);
+                    if (lp.blk_left && atomicSub(lp.blk_left + (b >> 5), 1) == 1) lp.blk_live[b >> 5] = 0;   // from the NEXT step on
+                }
             }
             // the last row of this launch publishes the step: ticket = arg-max launches so far, low word = rows stopped
             __threadfence();
@@ -685,6 +701,7 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
             }
         }
     }
+    if (dead) return;
     if (write_x) {
         __syncthreads();
         if (tid < 144) {

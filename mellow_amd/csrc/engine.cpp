@@ -148,10 +148,13 @@ struct mellow_engine {
     DecArgs da;
     int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
     int32_t *d_arrive = nullptr, *d_ticket = nullptr, *d_params = nullptr;   // loop bookkeeping words (LoopArgs)
+    int32_t *d_blk_left = nullptr, *d_blk_live = nullptr;                    // per-row-block early exit (32 blocks max)
+    const void* graph_blk = nullptr;                                         // DecArgs::blk_live the graphs were captured with
     unsigned long long* h_progress = nullptr;  // mapped host word the arg-max kernel publishes (ticket << 32 | rows stopped) to
     unsigned long long* d_progress = nullptr;  // its device alias
     std::map<std::pair<int, int>, float*> resample_banks;   // (orig, new) gcd-reduced -> device polyphase bank [klen][new]
     int32_t h_params[2] = {0, 0};              // staging of d_params {max_len, stop id}
+    int32_t h_blk[64] = {0};                   // staging of d_blk_left[32] | d_blk_live[32]
     int last_steps_enqueued = 0;               // decode steps (incl. the prefill's token) the last generate call enqueued
     Buf out_tok;                               // engine-owned token record [rows][max_len] (stable address: graph-safe)
     int kv_B = 0, kv_Tmax = 0;                // current page geometry
@@ -764,6 +767,8 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     e->d_arrive = e->d_tokens + 1027;
     e->d_ticket = e->d_tokens + 1028;
     e->d_params = e->d_tokens + 1032;
+    e->d_blk_left = e->d_tokens + 1040;
+    e->d_blk_live = e->d_tokens + 1072;
     e->d_seen = e->d_tokens + 2048;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped));
     *e->h_progress = 0;
@@ -1019,6 +1024,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
         float* p = e->dec.p;
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
+        a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
         a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
@@ -1065,6 +1071,7 @@ static LoopArgs loop_args(mellow_engine* e) {
     lp.out_tokens = reinterpret_cast<int32_t*>(e->out_tok.p);
     lp.params = e->d_params; lp.seen_stop = e->d_seen; lp.n_seen = e->d_nseen; lp.arrive = e->d_arrive; lp.ticket = e->d_ticket;
     lp.host_progress = e->d_progress; lp.T0 = e->cfg.prefix_len;
+    if (e->da.blk_live) { lp.blk_left = e->d_blk_left; lp.blk_live = e->d_blk_live; }
     return lp;
 }
 
@@ -1382,6 +1389,19 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     e->h_params[0] = max_len;
     e->h_params[1] = stop_id;
     HIPCHK(hipMemcpyAsync(e->d_params, e->h_params, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // Per-row-block early exit (reference stop rule, more than one 32-row block): once every row of a block has produced the
+    // stop id, the block's workgroups return at once in every later kernel (its rows' texts are already cut there).  Columns a
+    // row never reached are -1 in the token record.
+    e->da.blk_live = (!ignore_stop && e->da.RB > 1) ? e->d_blk_live : nullptr;
+    if (e->da.blk_live) {
+        for (int rb = 0; rb < 32; ++rb) {
+            const int left = B - 32 * rb;
+            e->h_blk[rb] = left <= 0 ? 0 : (left > 32 ? 32 : left);
+            e->h_blk[32 + rb] = left > 0 ? 1 : 0;
+        }
+        HIPCHK(hipMemcpyAsync(e->d_blk_left, e->h_blk, 64 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(e->out_tok.p, 0xff, (size_t)Bp * max_len * sizeof(int32_t), s));
+    }
     CHK(clear_page_tails(e, T));
     CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
     HIPCHK(hipEventRecord(e->ev_phase[1], s));
@@ -1393,7 +1413,8 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // one decode step = 30 x (qkv | attention | o_proj | gate/up | down) + final norm + lm_head + arg-max/record/embed,
     // captured once per (B, page geometry, buffers) and replayed; max_len and the stop id are read from d_params
     const bool graph = e->use_graph && !e->prof_on && max_len > 1;
-    if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tok != e->out_tok.p)) {
+    if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tok != e->out_tok.p ||
+                  e->graph_blk != e->da.blk_live)) {
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
         if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         hipGraph_t gr = nullptr;
@@ -1414,7 +1435,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         if (ce8 != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce8));
         HIPCHK(hipGraphInstantiate(&e->step_exec8, gr, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(gr));
-        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tok = e->out_tok.p;
+        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tok = e->out_tok.p; e->graph_blk = e->da.blk_live;
     }
     int steps_done = 1;   // token 0 came from the prefill
     double first_ms = -1.0;

@@ -110,6 +110,9 @@ struct DecArgs {
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)
     float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
+    // per-row-block early exit (reference stop rule, batches of more than one 32-row block): blk_live[rb] == 0 once every
+    // row of block rb has produced the stop id -- its workgroups return at once.  Null = never skip (one block / fixed length).
+    const int32_t* blk_live = nullptr;
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
@@ -132,6 +135,8 @@ struct LoopArgs {
     int32_t* n_seen = nullptr;
     int32_t* arrive = nullptr;           // rows that finished this step's arg-max (reset by the last one)
     int32_t* ticket = nullptr;           // arg-max launches since the start of the call
+    int32_t* blk_left = nullptr;         // [row blocks] rows of the block that have not produced the stop id yet
+    int32_t* blk_live = nullptr;         // [row blocks] cleared by the row that brings blk_left to 0 (DecArgs::blk_live)
     unsigned long long* host_progress = nullptr;   // mapped host memory
     int T0 = 0;                          // prefix length
 };

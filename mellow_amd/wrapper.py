@@ -175,18 +175,26 @@ class MellowWrapper:
             tensors = [one(f) for f in audio_files]
         return torch.cat(tensors, 0).to(self.model.tdev)
 
+    def _encode_padded(self, text, L):
+        """One prompt -> BatchEncoding padded / truncated to L ids.  The reference calls `tokenizer.encode_plus(...,
+        pad_to_max_length=True)` (wrapper.py:186-190, transformers 4.46); newer transformers spell the padding
+        `padding="max_length"`, and transformers >= 5 dropped `encode_plus` in favour of `tokenizer(...)` (same arguments)."""
+        enc = getattr(self.tokenizer, "encode_plus", None) or self.tokenizer
+        last = None
+        for pad_kw in ({"padding": "max_length"}, {"pad_to_max_length": True}):
+            try:
+                return enc(text=text, add_special_tokens=True, truncation=True, max_length=L, return_tensors="pt", **pad_kw)
+            except TypeError as e:      # this spelling is not known to the installed tokenizer
+                last = e
+        raise last
+
     def preprocess_text(self, prompts):
         """-> {'input_ids', 'attention_mask'} int64 (B, 129) (reference wrapper.py:181-195; the mask is never used)."""
         L = self.args.data["text_tokenization_len"]
         ids, masks = [], []
         for ttext in prompts:
             ttext = ttext + " <|endoftext|>" if "gpt" in self.args.model["decoder"]["text_decoder"] else ttext
-            try:
-                tok = self.tokenizer.encode_plus(text=ttext, add_special_tokens=True, truncation=True, max_length=L,
-                                                 padding="max_length", return_tensors="pt")
-            except TypeError:   # old transformers spelling used by the reference
-                tok = self.tokenizer.encode_plus(text=ttext, add_special_tokens=True, truncation=True, max_length=L,
-                                                 pad_to_max_length=True, return_tensors="pt")
+            tok = self._encode_padded(ttext, L)
             ids.append(torch.as_tensor(tok["input_ids"]).reshape(-1))
             masks.append(torch.as_tensor(tok["attention_mask"]).reshape(-1))
         return {"input_ids": torch.stack(ids, 0), "attention_mask": torch.stack(masks, 0)}
@@ -229,9 +237,8 @@ class MellowWrapper:
             from . import dist as mdist
             dev = self.model.tdev if dist.get_backend() == "nccl" else torch.device("cpu")
             toks, lens = mdist.gather_tokens(toks, lens, int(n_total), entry_length, device=dev)
-            rows = [r[r >= 0] for r in toks]          # -1 = padding of shards that stopped earlier
-        else:
-            rows = list(toks)
+        # -1 = never computed: padding of shards that stopped earlier, or steps after a whole 32-row block had stopped
+        rows = [r[r >= 0] for r in toks]
         return [self.tokenizer.decode(x).split("<|endoftext|>")[0] for x in rows]
 
     def generate(self, examples, max_len, top_p, temperature, stop_token="<|endoftext|>", audio_resample=True):

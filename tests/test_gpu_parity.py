@@ -342,6 +342,30 @@ def test_mixed_eos_matches_reference_cut_rule(engine, synth_sd, golden_dir):
     m.model.close()
 
 
+def test_row_block_early_exit(engine, golden_dir):
+    """B = 40 = two 32-row blocks under the reference stop rule: block 0 holds 32 copies of an example that produces the stop
+    id at step 3, block 1 rows that stop at steps 8 / 17 / never.  After step 3 block 0 is no longer computed (its columns stay
+    -1), block 1 is unaffected (tokens == the reference's), lengths follow the reference cut rule."""
+    g = np.load(os.path.join(golden_dir, "eos_mixed.npz"))
+    stop, L = int(g["stop_id"]), int(g["max_len"])
+    ex = g["one_never_examples"].tolist()                    # (1, 2, 4, 3): stop at 8, 17, 3, never
+    rows = [ex[2]] * 32 + [ex[0], ex[1], ex[3], ex[0], ex[1], ex[3], ex[0], ex[1]]
+    a1, a2, ids = synth.make_examples(rows)
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=L, stop_id=stop)
+    assert n == L                                            # the "never" rows keep the loop alive to max_len
+    want = {ex[i]: g[f"one_never_row{i}"] for i in range(4)}
+    free = {ex[i]: g["one_never_free_tokens"][i] for i in range(4)}
+    for r, e_ in enumerate(rows):
+        assert int(lens[r]) == len(want[e_]) and toks[r, : lens[r]].tolist() == want[e_].tolist(), r
+    assert np.array_equal(toks[:32, :4], np.tile(free[ex[2]][:4], (32, 1)))
+    assert (toks[:32, 5:] == -1).all()                       # block 0 stopped being computed (step 4 may still run)
+    for r in range(32, 40):
+        assert np.array_equal(toks[r], free[rows[r]][:L]), r
+    # the fixed-length mode never skips
+    t2, *_ = engine.generate(a1, a2, ids, max_len=8, stop_id=stop, ignore_stop=True)
+    assert (t2 >= 0).all() and np.array_equal(t2[:32], np.tile(free[ex[2]][:8], (32, 1)))
+
+
 def test_stop_at_first_token_and_nan_audio(engine, batch2, golden_dir):
     """Edges of the loop: (a) every row produces the stop id at step 0 -> one iteration, empty texts;
     (b) a NaN sample poisons its row only: torch.argmax treats NaN as the maximum, so that row decodes id 0 for ever

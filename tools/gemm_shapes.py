@@ -12,7 +12,8 @@ from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-eng = Engine(device=0, max_positions=1024)
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
+eng = Engine(device=0, precision=PREC)
 eng.load_state_dict(synth.make_state_dict(0))
 a1, a2, ids = synth.make_batch(B)
 a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
