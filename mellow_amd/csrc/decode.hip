@@ -40,12 +40,22 @@ void set_kernel_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 // softmax weights: exp(x) = 2^(x*log2 e) on the hardware v_exp_f32 (x <= 0 here; ~1e-6 relative, far inside the fp32
 // summation-order noise of a 64..700-key softmax); exp(-inf) = 0 exactly
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// A/B switches for developer builds (tools/ab_build.sh): -DMELLOW_NO_BLK_EXIT, -DMELLOW_NO_NT
+#ifdef MELLOW_NO_BLK_EXIT
+#define MELLOW_BLK_EXIT(RB)
+#else
+#define MELLOW_BLK_EXIT(RB) if (BLK) { if (a.blk_live[RB] == 0) return; }   // BLK: compile-time (a run-time null test costs 0.26 us per launch)
+#endif
 // streamed-once operands (weights, KV pages): non-temporal loads (`global_load_dwordx4 ... nt`).  Each of these lines is read
 // by exactly one workgroup per step, so keeping it in L2 buys nothing, and the nt policy shortens issue -> landed by ~18 %
 // on this part (MI355X_MICROARCH.md, row nt-weights)
 __device__ __forceinline__ float4 ldg_nt(const float4* p) {
+#ifdef MELLOW_NO_NT
+    return *p;
+#else
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
+#endif
 }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
@@ -66,7 +76,7 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 //     X = baseF + sum_{s<KCD} dslabF[s]  (residual stream, un-normalised; norm weight folded into W)
 //     out: pq[kc][row][960] row-major slabs (consumer = attention, row-parallel)
 // ----------------------------------------------------------------------------------------------------
-template <int KCD>
+template <int KCD, bool BLK, bool FIRST>
 __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
     __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
     __shared__ float ssq_s[3 * 32];
@@ -76,14 +86,14 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
     // The first kernel of a step (a.first): advance the position word (nothing of the previous step reads it any more)
     // and stage this position's RoPE row at a fixed address, so that no attention kernel of the step has to chase
     // pos -> table row (two dependent round trips).  One half-wave: the loads of *d_pos precede the store in program order.
-    if (a.first && nt == 29 && kc == 0 && rb == 0 && tid < 32) {
+    if (FIRST && nt == 29 && kc == 0 && rb == 0 && tid < 32) {     // FIRST: compile-time, like BLK
         const int p = *a.d_pos + a.inc_pos;
         const float c = a.rope_cos[(int64_t)p * 32 + tid], sn = a.rope_sin[(int64_t)p * 32 + tid];
         a.rope_cur[tid] = c;
         a.rope_cur[32 + tid] = sn;
         if (tid == 0 && a.inc_pos) *a.d_pos = p;
     }
-    if (a.blk_live && a.blk_live[rb] == 0) return;      // every row of this block has stopped (workgroup-uniform)
+    MELLOW_BLK_EXIT(rb)      // every row of this block has stopped (workgroup-uniform)
     if (wave < 3) {
         const int k8_0 = (kc * 3 + wave) * KPW;
         const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
@@ -146,16 +156,18 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
 constexpr int DA_WAVES = 8;
 constexpr int DA_G = 7;          // 4-key groups in flight per wave: one chunk covers 2*8*7*4 = 448 keys
 
+template <bool BLK>
 __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
                                                                   float* __restrict__ v_cache) {
     __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
     __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
+    __shared__ __attribute__((aligned(16))) float xs[320];               // q (3 x 64) | k | v before RoPE, RMS-scaled
     __shared__ __attribute__((aligned(16))) float ored[DA_WAVES * 3 * 64];
     __shared__ float mred[DA_WAVES * 3], lred[DA_WAVES * 3];
     __shared__ float snew_s[3];
 
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
-    if (a.blk_live && a.blk_live[b >> 5] == 0) return;
+    MELLOW_BLK_EXIT(b >> 5)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tmax = a.Tmax;
     float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
@@ -168,19 +180,20 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const bool dbg = tid == 0 && g == 0 && b == 0 && sp == 0;
     kstamp(1, 0, dbg);
     const int pos = *a.d_pos;        // keys 0..pos-1 are cached; the new key is key `pos`
-    // prologue role (branch-free addressing; results masked on use):
-    //   tid <128 : hsel = tid>>5 (0..2 = query head 3g+hsel, 3 = new key), elements i = tid&31 and i+32
-    //   tid <192 : new value element tid-128
+    // prologue: the 320 projected values of this (row, kv head) -- q of 3 heads | k | v -- are the sums of the qkv kernel's
+    // split-K slabs.  80 threads own one float4 of columns each (8 slab loads of 16 B; before: 512 threads x 16 dword loads),
+    // scale by the RMS statistic and park the result in LDS; 192 threads then apply RoPE / append the new key and value.
+    //   r <48: query head 3g + r/16, columns 4(r%16)..   r <64: key columns 4(r-48)..   r <80: value columns 4(r-64)..
     const int hsel = (tid >> 5) & 3, i = tid & 31;
-    const int col1 = tid < 128 ? (hsel < 3 ? (3 * g + hsel) * 64 : 576 + g * 64) + i : 768 + g * 64 + ((tid - 128) & 63);
-    const int col2 = tid < 128 ? col1 + 32 : col1;
-    const float* prow = a.pq + (int64_t)b * 960;
-    float a1[DEC_KC_QKV], a2[DEC_KC_QKV], sq[DEC_KC_QKV];
+    const int r = tid < 80 ? tid : 0;
+    const int pcol = r < 48 ? (3 * g + (r >> 4)) * 64 + 4 * (r & 15) : r < 64 ? 576 + g * 64 + 4 * (r - 48) : 768 + g * 64 + 4 * (r - 64);
+    const float* prow = a.pq + (int64_t)b * 960 + pcol;
+    float4 sl4[DEC_KC_QKV], sq4[2];
+    if (tid < 80) {
 #pragma unroll
-    for (int s = 0; s < DEC_KC_QKV; ++s) {
-        a1[s] = prow[(int64_t)s * a.rows * 960 + col1];
-        a2[s] = prow[(int64_t)s * a.rows * 960 + col2];
-        sq[s] = a.ssq1[(int64_t)b * DEC_KC_QKV + s];
+        for (int s = 0; s < DEC_KC_QKV; ++s) sl4[s] = *reinterpret_cast<const float4*>(prow + (int64_t)s * a.rows * 960);
+        sq4[0] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[0];
+        sq4[1] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[1];
     }
     const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
     const int gbeg = sp * a.gs;                                   // groups of 4 keys
@@ -198,14 +211,19 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 
     const int ngroups = (pos + 3) >> 2;                           // groups of 4 cached keys
     const int gend = min(ngroups, gend_fixed);
-    float x1 = a1[0], x2 = a2[0];
+    static_assert(DEC_KC_QKV == 8, "fixed summation order below");
+    if (tid < 80) {
+        float4 x = sl4[0];
 #pragma unroll
-    for (int s = 1; s < DEC_KC_QKV; ++s) { x1 += a1[s]; x2 += a2[s]; }
-    static_assert(DEC_KC_QKV == 8, "fixed summation tree below");
-    const float ssum = ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
-    const float rscale = 1.0f / sqrtf(ssum / 576.0f + a.eps);
-    x1 *= rscale; x2 *= rscale;
+        for (int s = 1; s < DEC_KC_QKV; ++s) x = f4add(x, sl4[s]);           // slab 0, then 1, ... (the order of every build)
+        const float ssum = ((sq4[0].x + sq4[0].y) + (sq4[0].z + sq4[0].w)) + ((sq4[1].x + sq4[1].y) + (sq4[1].z + sq4[1].w));
+        const float rscale = 1.0f / sqrtf(ssum / 576.0f + a.eps);
+        *reinterpret_cast<float4*>(xs + 4 * tid) = make_float4(x.x * rscale, x.y * rscale, x.z * rscale, x.w * rscale);
+    }
+    __syncthreads();
     if (tid < 128) {
+        const int base = hsel < 3 ? hsel * 64 : 192;
+        const float x1 = xs[base + i], x2 = xs[base + i + 32];
         const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sn));
         const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
         if (hsel < 3) {
@@ -216,6 +234,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             if (sp == 0) { kpage[(int64_t)pos * 64 + i] = o1; kpage[(int64_t)pos * 64 + i + 32] = o2; }
         }
     } else if (tid < 192) {
+        const float x1 = xs[256 + tid - 128];
         vnew[tid - 128] = x1;
         if (sp == 0) vpage[(int64_t)pos * 64 + (tid - 128)] = x1;
     }
@@ -343,12 +362,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 //     halves doubles the workgroups (72) and halves the activation bytes each CU has to pull.
 //     writes x_mid row-major + F32-layout (next layer's qkv) + F16-layout (gate/up) + per-tile sum of squares
 // ----------------------------------------------------------------------------------------------------
+template <bool BLK>
 __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
     __shared__ __attribute__((aligned(16))) float red[16 * 4 * 64];   // 16 KiB: [wave][acc reg][lane]
     constexpr int TPW = 3, K16 = 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
-    if (a.blk_live && a.blk_live[rb] == 0) return;
+    MELLOW_BLK_EXIT(rb)
     const int ml = lane & 15;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + (int64_t)nt * K16 * 64 + lane;
     // epilogue operand issued up front: thread (m, nq) of the 16 x 16 tile owns 4 consecutive columns
@@ -422,14 +442,14 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
 //     wave in flight; X in F32-layout.  Writes row-major logits (optional) + fused arg-max candidates per tile.
 // ----------------------------------------------------------------------------------------------------
 enum { OUT_LOGITS = 1 };
-template <int OUT>
+template <int OUT, bool BLK>
 __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                         const float* __restrict__ XF, int N) {
     __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
     constexpr int KPW = 18;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.z;
-    if (a.blk_live && a.blk_live[rb] == 0) return;
+    MELLOW_BLK_EXIT(rb)
     const int k8_0 = wave * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
@@ -496,12 +516,13 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
 //     epilogue: r2[m] = rsqrt(mean(x_mid[m]^2) + eps) from the o_proj's per-tile sums;
 //     h = silu(r2 g) * (r2 u)  ->  hF[rb][hidden/8][lane][4]  (F32-layout B operand of the down projection)
 // ----------------------------------------------------------------------------------------------------
+template <bool BLK>
 __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
     __shared__ __attribute__((aligned(16))) float red[4 * 8 * 64];   // 8 KiB
     constexpr int TPW = 9, K16 = 36;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y;
-    if (a.blk_live && a.blk_live[rb] == 0) return;
+    MELLOW_BLK_EXIT(rb)
     const int t0 = wave * TPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * K16 + t0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
@@ -565,12 +586,13 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
 // K5  down projection, split-K.  grid (18 n-tiles, DEC_KC_DOWN, RB), 6 waves x 4 k-tiles.
 //     X = h (SwiGLU output of K4b, F32-layout);  out: down slabs in F32-layout (next layer's qkv / final norm)
 // ----------------------------------------------------------------------------------------------------
+template <bool BLK>
 __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
     __shared__ __attribute__((aligned(16))) float red[6 * 16 * 64];   // 24 KiB
     constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
-    if (a.blk_live && a.blk_live[rb] == 0) return;
+    MELLOW_BLK_EXIT(rb)
     const int k8_0 = (kc * 6 + wave) * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
@@ -615,11 +637,11 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
 // row-parallel helpers (one workgroup per batch row)
 // ----------------------------------------------------------------------------------------------------
 // final RMSNorm: xn = w * ((x_mid + sum down slabs) * rsqrt(mean^2 + eps)) -> F32-layout operand of the lm_head
-template <int KCD>
+template <int KCD, bool BLK>
 __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, const float* __restrict__ norm_w) {
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (a.blk_live && a.blk_live[b >> 5] == 0) return;
+    MELLOW_BLK_EXIT(b >> 5)
     const int xi = tid < 144 ? tid : 0;
     const int64_t fi = f32_idx(b >> 5, 72, b & 31, xi * 4);
     float4 v = reinterpret_cast<const float4*>(a.xmidF)[fi];
@@ -725,30 +747,51 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------
+// BLK = per-row-block early exit compiled in (a.blk_live != null): two instantiations, chosen on the host
+#define MELLOW_LAUNCH_BLK(KERNEL, GRID, BLOCK, ...)                                                               \
+    do {                                                                                                         \
+        if (a.blk_live) hipLaunchKernelGGL((KERNEL<true>), GRID, BLOCK, 0, s, __VA_ARGS__);                       \
+        else hipLaunchKernelGGL((KERNEL<false>), GRID, BLOCK, 0, s, __VA_ARGS__);                                 \
+    } while (0)
 void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStream_t s) {
     const dim3 grid(30, DEC_KC_QKV, a.RB);
-    if (kcd == 0) hipLaunchKernelGGL((dec_qkv_kernel<0>), grid, dim3(256), 0, s, a, Wp, K8p);
-    else hipLaunchKernelGGL((dec_qkv_kernel<DEC_KC_DOWN>), grid, dim3(256), 0, s, a, Wp, K8p);
+    // the first qkv launch of a step (a.first) always starts from a materialised x (kcd == 0); later ones sum the down slabs
+#define MELLOW_QKV(KCD, FIRST)                                                                              \
+    do {                                                                                                    \
+        if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST>), grid, dim3(256), 0, s, a, Wp, K8p);   \
+        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST>), grid, dim3(256), 0, s, a, Wp, K8p);             \
+    } while (0)
+    if (kcd == 0 && a.first) MELLOW_QKV(0, true);
+    else if (kcd == 0) MELLOW_QKV(0, false);
+    else if (a.first) MELLOW_QKV(DEC_KC_DOWN, true);
+    else MELLOW_QKV(DEC_KC_DOWN, false);
+#undef MELLOW_QKV
 }
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s) {
-    hipLaunchKernelGGL(dec_attn_kernel, dim3(3, a.rows, DEC_TS), dim3(DA_WAVES * 64), 0, s, a, k_cache, v_cache);
+    MELLOW_LAUNCH_BLK(dec_attn_kernel, dim3(3, a.rows, DEC_TS), dim3(DA_WAVES * 64), a, k_cache, v_cache);
 }
 int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    hipLaunchKernelGGL(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(1024), 0, s, a, Wp16);
+    MELLOW_LAUNCH_BLK(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(1024), a, Wp16);
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    hipLaunchKernelGGL(dec_gateup16_kernel, dim3(192, a.RB), dim3(256), 0, s, a, Wp16);
+    MELLOW_LAUNCH_BLK(dec_gateup16_kernel, dim3(192, a.RB), dim3(256), a, Wp16);
 }
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
-    hipLaunchKernelGGL(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(384), 0, s, a, Wp, K8p);
+    MELLOW_LAUNCH_BLK(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(384), a, Wp, K8p);
 }
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s) {
-    if (kcd == 0) hipLaunchKernelGGL((dec_final_norm_kernel<0>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
-    else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+    if (kcd == 0) {
+        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<0, true>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+        else hipLaunchKernelGGL((dec_final_norm_kernel<0, false>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+    } else {
+        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, true>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+        else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, false>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+    }
 }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
+    if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
+    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
 }
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
                        const LoopArgs& loop, hipStream_t s) {

@@ -1393,7 +1393,11 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // stop id, the block's workgroups return at once in every later kernel (its rows' texts are already cut there).  Columns a
     // row never reached are -1 in the token record.
     e->da.blk_live = (!ignore_stop && e->da.RB > 1) ? e->d_blk_live : nullptr;
-    if (e->da.blk_live) {
+    static const bool dev_dead = getenv("MELLOW_DEV_DEAD_BLOCKS") != nullptr;    // developer probe: launch-chain floor of a step
+    if (dev_dead) {
+        e->da.blk_live = e->d_blk_live;
+        HIPCHK(hipMemsetAsync(e->d_blk_left, 0, 64 * sizeof(int32_t), s));
+    } else if (e->da.blk_live) {
         for (int rb = 0; rb < 32; ++rb) {
             const int left = B - 32 * rb;
             e->h_blk[rb] = left <= 0 ? 0 : (left > 32 ? 32 : left);

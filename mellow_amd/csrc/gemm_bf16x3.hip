@@ -30,6 +30,12 @@ __device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l)
     l = static_cast<__bf16>(r2);                      // exact
 }
 __device__ __forceinline__ void split8(const float (&v)[8], i32x4& p0, i32x4& p1, i32x4& p2) {
+#ifdef MELLOW_X3_FAKESPLIT      // developer A/B build only: wrong numbers, no VALU work (is the split what bounds the loop?)
+    p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+    p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
+    p2 = p0;
+    return;
+#endif
     bf16x8 h, m, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -291,6 +297,142 @@ __global__ __launch_bounds__(256) void gemm_bf16x3f_kernel(const GemmBDev p) {
     }
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
+
+// ---- software-pipelined variant of the fused kernel ("x3p") ---------------------------------------------------------------
+// What the counters of the kernel above say (rocprofv3 --pmc on the K = 4608 steady state, profiles/r02_pmc_x3_loop.txt): the
+// matrix pipe is busy 39 % of the time, the VALU (operand split) 25 %, and the two co-execute in only 4 % of the cycles: a wave
+// reads its fragments, splits them, issues its 24 MFMAs and then stores / waits at the barrier, so with ~2 waves per SIMD the
+// pipe idles whenever both are outside their MFMA burst.  Here the bursts are made continuous inside ONE wave:
+//   * three LDS stages (k16 each): tile t+2 is being written while tile t is multiplied, so tile t+1 is already complete and
+//     its fragments are read + split DURING the MFMAs of tile t (fragments double-buffered in registers);
+//   * sched_group_barrier interleaves those LDS reads / VALU ops / global loads between the MFMA issues;
+//   * still one barrier per k16, but nothing waits on it: after the barrier the next tile's fragments are in registers.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
+    constexpr int BM = 128, BN = 128, WN = 2, NST = 3;
+    constexpr int STAGE = 3 * 4 * 64;                                       // 16-byte slots per operand per stage: [piece][tile][lane]
+    extern __shared__ __attribute__((aligned(16))) i32x4 smem_bf[];
+    i32x4* As = smem_bf;                                                    // [NST][STAGE]  A already split (3 bf16 pieces)
+    i32x4* Ws = smem_bf + NST * STAGE;                                      // [NST][STAGE]
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
+    const int pm = L / p.gn, pn = L % p.gn;
+    const int KT = g.K >> 4;
+    const i32x4* PB = reinterpret_cast<const i32x4*>(g.W8);
+
+    // A staging: thread t owns the 8 consecutive k of (row t/2, k-half t%2) of a k16 tile = exactly one lane's share of an MFMA
+    // operand: it loads 32 contiguous bytes, splits them ONCE for the whole workgroup and writes the three bf16 pieces
+    const int arow = tid >> 1, akh = tid & 1;
+    int am = pm * BM + arow;
+    am = am < g.M ? am : g.M - 1;
+    const float* a_ptr = g.A + (int64_t)am * g.lda + akh * 8;
+    const int a_lds = (arow >> 5) * 64 + (arow & 31) + 32 * akh;            // + piece * 256
+    const i32x4* w_ptr[3];
+    int w_lds[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int c = q * 256 + tid;
+        const int ntl = c / 192, r2 = c % 192;           // W: [n-tile][piece][lane] per k16
+        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * KT) * 192 + r2;
+        w_lds[q] = ((r2 >> 6) * 4 + ntl) * 64 + (r2 & 63);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // two register sets: a tile's global loads are issued two whole iterations before its LDS store (an L2 round trip is
+    // longer than one 24-MFMA iteration)
+    f32x4 raA[2], raB[2];
+    i32x4 rwA[3], rwB[3];
+#define X3_GLOAD(T, ra, rw)                                                                      \
+    {                                                                                            \
+        const int t_ = (T) < KT ? (T) : KT - 1;                                                  \
+        ra[0] = *reinterpret_cast<const f32x4*>(a_ptr + t_ * 16);                                \
+        ra[1] = *reinterpret_cast<const f32x4*>(a_ptr + t_ * 16 + 4);                            \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) rw[q] = w_ptr[q][(int64_t)t_ * 192];       \
+    }
+#define X3_LSTORE(ST, ra, rw)                                                                    \
+    {                                                                                            \
+        const float v_[8] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w, ra[1].x, ra[1].y, ra[1].z, ra[1].w}; \
+        i32x4 p0_, p1_, p2_;                                                                     \
+        split8(v_, p0_, p1_, p2_);                                                               \
+        As[(ST) * STAGE + a_lds] = p0_;                                                          \
+        As[(ST) * STAGE + 256 + a_lds] = p1_;                                                    \
+        As[(ST) * STAGE + 512 + a_lds] = p2_;                                                    \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) Ws[(ST) * STAGE + w_lds[q]] = rw[q];        \
+    }
+    // fragments of one k16 tile: a[m-tile][piece], w[n-tile][piece]
+#define X3_FRAGS(ST, FA, FW)                                                                     \
+    {                                                                                            \
+        const i32x4* Ac = As + (ST) * STAGE + (2 * wm) * 64 + lane;                              \
+        const i32x4* Wc = Ws + (ST) * STAGE + (2 * wn) * 64 + lane;                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                            \
+            _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                   \
+                FA[t][pc] = Ac[(pc * 4 + t) * 64];                                               \
+                FW[t][pc] = Wc[(pc * 4 + t) * 64];                                               \
+            }                                                                                    \
+    }
+#define X3_TERM(FA, FW, PW, PA)                         \
+    MELLOW_BF(FW[0][PW], FA[0][PA], acc[0][0])          \
+    MELLOW_BF(FW[0][PW], FA[1][PA], acc[0][1])          \
+    MELLOW_BF(FW[1][PW], FA[0][PA], acc[1][0])          \
+    MELLOW_BF(FW[1][PW], FA[1][PA], acc[1][1])
+#define X3_MFMAS(FA, FW) X3_TERM(FA, FW, 2, 0) X3_TERM(FA, FW, 0, 2) X3_TERM(FA, FW, 1, 1) X3_TERM(FA, FW, 1, 0) X3_TERM(FA, FW, 0, 1) X3_TERM(FA, FW, 0, 0)
+    // interleave between the MFMA issues: the 12 fragment reads of the next tile first, then the split of the staged tile
+    // (VALU) with its 6 LDS writes, then the 5 global loads of the tile after that
+#define X3_SCHED()                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        if (i_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+        if (i_ >= 2 && i_ < 14) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               \
+        if (i_ >= 14 && i_ < 20) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              \
+        if (i_ >= 19 && i_ < 24) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              \
+    }
+
+    i32x4 fa0[2][3], fw0[2][3], fa1[2][3], fw1[2][3];
+    X3_GLOAD(0, raA, rwA)
+    X3_GLOAD(1, raB, rwB)
+    X3_LSTORE(0, raA, rwA)
+    X3_LSTORE(1, raB, rwB)
+    X3_GLOAD(2, raA, rwA)
+    X3_GLOAD(3, raB, rwB)
+    __syncthreads();
+    X3_FRAGS(0, fa0, fw0)
+    // iteration t: fragments of tile t+1 (complete since the last barrier) -> registers; MFMAs of tile t; registers (tile t+2,
+    // loaded one whole iteration ago) split -> stage (t+2) % 3, whose last readers finished in iteration t-2; loads of tile
+    // t+4 -> the same registers (two sets alternate); barrier.  Unrolled by 6: stage indices and register sets are static.
+#define X3_ITER(T, SN, SW, FA, FW, FAN, FWN, ra, rw)                                             \
+    if ((T) < KT) {                                                                              \
+        X3_FRAGS(SN, FAN, FWN)                                                                   \
+        X3_MFMAS(FA, FW)                                                                         \
+        X3_LSTORE(SW, ra, rw)                                                                    \
+        X3_GLOAD((T) + 4, ra, rw)                                                                \
+        X3_SCHED()                                                                               \
+        __syncthreads();                                                                         \
+    }
+    for (int kt = 0; kt < KT; kt += 6) {
+        X3_ITER(kt + 0, 1, 2, fa0, fw0, fa1, fw1, raA, rwA)
+        X3_ITER(kt + 1, 2, 0, fa1, fw1, fa0, fw0, raB, rwB)
+        X3_ITER(kt + 2, 0, 1, fa0, fw0, fa1, fw1, raA, rwA)
+        X3_ITER(kt + 3, 1, 2, fa1, fw1, fa0, fw0, raB, rwB)
+        X3_ITER(kt + 4, 2, 0, fa0, fw0, fa1, fw1, raA, rwA)
+        X3_ITER(kt + 5, 0, 1, fa1, fw1, fa0, fw0, raB, rwB)
+    }
+#undef X3_GLOAD
+#undef X3_LSTORE
+#undef X3_FRAGS
+#undef X3_TERM
+#undef X3_MFMAS
+#undef X3_SCHED
+#undef X3_ITER
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
+}
 #undef MELLOW_BF
 
 template <int EPI>
@@ -309,6 +451,17 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
     static const int ks16 = getenv("MELLOW_F32X3_KS16") ? atoi(getenv("MELLOW_F32X3_KS16")) : 1;   // k16 steps per LDS stage
+    static const bool pipelined = !(getenv("MELLOW_X3_KERNEL") && getenv("MELLOW_X3_KERNEL")[0] == 'f');   // 'f' = the plain fused kernel
+    if (pipelined && a.K % 16 == 0 && a.K >= 192) {      // shorter K: the 3-stage prologue costs more than it hides (K = 96: 77 vs 84 TF)
+        const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                          // 72 KiB
+        static bool attr_p = false;
+        if (!attr_p) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_p = true;
+        }
+        hipLaunchKernelGGL((gemm_x3p_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+        return;
+    }
     if (ks16 == 2 && a.K % 32 == 0) {
         const size_t lds = (size_t)2 * (2 * 2 * 4 * 64 + 2 * 3 * 4 * 64) * 16;     // 80 KiB
         static bool attr_set = false;

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
-eng = Engine(device=0, max_positions=1024)
+eng = Engine(device=0)
 eng.load_state_dict(synth.make_state_dict(0))
 B = 32
 a1, a2, ids = synth.make_batch(B)
