@@ -179,7 +179,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     //       so their addresses do not wait for the position; keys >= pos are masked after the loads land) =====
     const bool dbg = tid == 0 && g == 0 && b == 0 && sp == 0;
     kstamp(1, 0, dbg);
+#ifdef MELLOW_POS_VECTOR_LOAD
+    const int pos = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(a.d_pos));
+#else
     const int pos = *a.d_pos;        // keys 0..pos-1 are cached; the new key is key `pos`
+#endif
     // prologue: the 320 projected values of this (row, kv head) -- q of 3 heads | k | v -- are the sums of the qkv kernel's
     // split-K slabs.  80 threads own one float4 of columns each (8 slab loads of 16 B; before: 512 threads x 16 dword loads),
     // scale by the RMS statistic and park the result in LDS; 192 threads then apply RoPE / append the new key and value.

@@ -1025,6 +1025,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
         a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
+        // (and the logits store off: the taps mellow_lm_prefill / mellow_lm_decode_step read dlogits, generation does not)
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
         a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
@@ -1392,6 +1393,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // Per-row-block early exit (reference stop rule, more than one 32-row block): once every row of a block has produced the
     // stop id, the block's workgroups return at once in every later kernel (its rows' texts are already cut there).  Columns a
     // row never reached are -1 in the token record.
+    e->da.logits = nullptr;             // generation needs the arg-max candidates only: no 6 MB logits store per step
     e->da.blk_live = (!ignore_stop && e->da.RB > 1) ? e->d_blk_live : nullptr;
     static const bool dev_dead = getenv("MELLOW_DEV_DEAD_BLOCKS") != nullptr;    // developer probe: launch-chain floor of a step
     if (dev_dead) {

@@ -306,7 +306,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3f_kernel(const GemmBDev p) {
 //   * three LDS stages (k16 each): tile t+2 is being written while tile t is multiplied, so tile t+1 is already complete and
 //     its fragments are read + split DURING the MFMAs of tile t (fragments double-buffered in registers);
 //   * sched_group_barrier interleaves those LDS reads / VALU ops / global loads between the MFMA issues;
-//   * still one barrier per k16, but nothing waits on it: after the barrier the next tile's fragments are in registers.
+//   * still one barrier per k16, but nothing waits on it: after the barrier the next tile's fragments are in registers;
+//   * A is split ONCE per workgroup when it is staged into LDS (the fused kernel split it in every consuming wave);
+//   * a tile's global loads are issued two whole iterations before its LDS store.
+// Measured (tools/f32x3_bench.py, random data): LM shapes 131/119/131/128 -> 148/144/160/167 TFLOP/s-equivalent, K = 4608
+// steady state 167 -> 189.  Also measured and NOT kept: loading the weight fragments straight from global memory in fragment
+// order (no LDS for W, half the LDS operations): 188.7 vs 189.2 -- LDS issue is not what bounds the loop; a free (wrong)
+// operand split: 206 -- the VALU is not either.  What remains is the one barrier per 24 MFMAs with two waves per SIMD.
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     constexpr int BM = 128, BN = 128, WN = 2, NST = 3;
@@ -433,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
 #undef X3_ITER
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
+
 #undef MELLOW_BF
 
 template <int EPI>
