@@ -153,8 +153,12 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
 //     per-wave online softmax over an interleaved set of 4-key groups; partial (m, l, o) per split.
 //     Split sp owns key groups [sp*gs, (sp+1)*gs) (the last split: everything from sp*gs on, plus the new key).
 // ----------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 8;
-constexpr int DA_G = 7;          // 4-key groups in flight per wave: one chunk covers 2*8*7*4 = 448 keys
+#ifndef MELLOW_DA_WAVES
+#define MELLOW_DA_WAVES 8
+#define MELLOW_DA_G 7
+#endif
+constexpr int DA_WAVES = MELLOW_DA_WAVES;
+constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chunk covers 2 * DA_WAVES * DA_G * 4 = 448 keys
 
 template <bool BLK>
 __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
@@ -366,10 +370,16 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 //     halves doubles the workgroups (72) and halves the activation bytes each CU has to pull.
 //     writes x_mid row-major + F32-layout (next layer's qkv) + F16-layout (gate/up) + per-tile sum of squares
 // ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_OPROJ_WAVES
+#define MELLOW_OPROJ_WAVES 12
+#endif
+// waves per workgroup: 12 x 3 k16-tiles = the 36 tiles exactly (16 x 3 left 12 empty slots whose loads were still issued:
+// +1.1 ms of decode per 63 steps, measured on one box with tools/ab_build.sh)
+constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
 template <bool BLK>
-__global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
-    __shared__ __attribute__((aligned(16))) float red[16 * 4 * 64];   // 16 KiB: [wave][acc reg][lane]
-    constexpr int TPW = 3, K16 = 36;
+__global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+    __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
+    constexpr int K16 = 36, TPW = (K16 + OP_WAVES - 1) / OP_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
     MELLOW_BLK_EXIT(rb)
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
     const int64_t row = (int64_t)rb * 32 + mh * 16 + ml;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 16 * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
+        const int t = wave + OP_WAVES * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
         w[i] = ldg_nt(wp + (int64_t)tc * 64);
         if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int h = tc >> 2;                                        // tile = 16 k of head h
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
         const int src_lane = em + 16 * enq;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int wv = 0; wv < 16; ++wv)
+        for (int wv = 0; wv < OP_WAVES; ++wv)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += red[(wv * 4 + r) * 64 + src_lane];
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(1024) void dec_oproj_kernel(const DecArgs a, const 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// (measured and not kept: two 32-column tiles per workgroup sharing the x registers, 768 workgroups: 38.9 vs 36.7 us)
 // K4  full-K projection (lm_head).  grid (n-tiles, 1, RB), 4 waves x 18 k-tiles, all 36 loads of a
 //     wave in flight; X in F32-layout.  Writes row-major logits (optional) + fused arg-max candidates per tile.
 // ----------------------------------------------------------------------------------------------------
@@ -590,14 +601,18 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
 // K5  down projection, split-K.  grid (18 n-tiles, DEC_KC_DOWN, RB), 6 waves x 4 k-tiles.
 //     X = h (SwiGLU output of K4b, F32-layout);  out: down slabs in F32-layout (next layer's qkv / final norm)
 // ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_DOWN_WAVES
+#define MELLOW_DOWN_WAVES 6
+#endif
+constexpr int DN_WAVES = MELLOW_DOWN_WAVES;       // 6 x 4 k-tiles or 8 x 3 (two waves on every SIMD)
 template <bool BLK>
-__global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
-    __shared__ __attribute__((aligned(16))) float red[6 * 16 * 64];   // 24 KiB
-    constexpr int KPW = 192 / (DEC_KC_DOWN * 6);   // 4
+__global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+    __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
+    constexpr int KPW = 192 / (DEC_KC_DOWN * DN_WAVES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
     MELLOW_BLK_EXIT(rb)
-    const int k8_0 = (kc * 6 + wave) * KPW;
+    const int k8_0 = (kc * DN_WAVES + wave) * KPW;
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
     const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(384) void dec_down_kernel(const DecArgs a, const fl
             const int q = 4 * gq + j;
             float sacc = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < 6; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];
+            for (int wv = 0; wv < DN_WAVES; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];
             v[j] = sacc;
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
@@ -776,13 +791,13 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream
 }
 int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(1024), a, Wp16);
+    MELLOW_LAUNCH_BLK(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), a, Wp16);
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s) {
     MELLOW_LAUNCH_BLK(dec_gateup16_kernel, dim3(192, a.RB), dim3(256), a, Wp16);
 }
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(384), a, Wp, K8p);
+    MELLOW_LAUNCH_BLK(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), a, Wp, K8p);
 }
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s) {
     if (kcd == 0) {
