@@ -457,11 +457,15 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
 //     wave in flight; X in F32-layout.  Writes row-major logits (optional) + fused arg-max candidates per tile.
 // ----------------------------------------------------------------------------------------------------
 enum { OUT_LOGITS = 1 };
+#ifndef MELLOW_LM_WAVES
+#define MELLOW_LM_WAVES 8     // 8 x 9 k-tiles: 53.45 vs 54.35 ms of decode per 63 steps with 4 x 18 (6 / 9 / 12 waves: 54.1 / 54.1 / 53.7)
+#endif
+constexpr int LM_WAVES = MELLOW_LM_WAVES;
 template <int OUT, bool BLK>
-__global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
+__global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                         const float* __restrict__ XF, int N) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-    constexpr int KPW = 18;
+    __shared__ __attribute__((aligned(16))) float red[LM_WAVES * 16 * 64];
+    constexpr int KPW = 72 / LM_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.z;
     MELLOW_BLK_EXIT(rb)
@@ -486,18 +490,21 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
     kstamp(dslot, 3, dbg);
-    const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
+    const bool epi = tid < 256;             // the epilogue is 256 threads wide (more waves only with MELLOW_LM_WAVES > 4)
+    const int mm = tid & 31, hh = (tid >> 5) & 1, gq = (tid >> 6) & 3;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 4 * gq + j;
-        v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) +
-               (red[(2 * 16 + r) * 64 + mm + 32 * hh] + red[(3 * 16 + r) * 64 + mm + 32 * hh]);
+        float sacc = red[r * 64 + mm + 32 * hh];
+#pragma unroll
+        for (int wv = 1; wv < LM_WAVES; ++wv) sacc += red[(wv * 16 + r) * 64 + mm + 32 * hh];      // fixed order
+        v[j] = sacc;
     }
     {
         const int n = nt * 32 + 8 * gq + 4 * hh;
         const int64_t row = (int64_t)rb * 32 + mm;
-        if (a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (epi && a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
         // best (value, lowest index) of this 32-column tile per row (torch.argmax tie rule)
         __syncthreads();
         float bv = v[0];
@@ -505,8 +512,10 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
 #pragma unroll
         for (int j = 1; j < 4; ++j)
             if (arg_better(v[j], n + j, bv, bi)) { bv = v[j]; bi = n + j; }
-        red[tid] = bv;
-        reinterpret_cast<int*>(red)[256 + tid] = bi;
+        if (epi) {
+            red[tid] = bv;
+            reinterpret_cast<int*>(red)[256 + tid] = bi;
+        }
         __syncthreads();
         if (tid < 32) {
             float best = red[tid];
@@ -531,10 +540,15 @@ __global__ __launch_bounds__(256) void dec_fullk_kernel(const DecArgs a, const f
 //     epilogue: r2[m] = rsqrt(mean(x_mid[m]^2) + eps) from the o_proj's per-tile sums;
 //     h = silu(r2 g) * (r2 u)  ->  hF[rb][hidden/8][lane][4]  (F32-layout B operand of the down projection)
 // ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_GU_WAVES
+#define MELLOW_GU_WAVES 4
+#endif
+constexpr int GU_WAVES = MELLOW_GU_WAVES;
 template <bool BLK>
-__global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 8 * 64];   // 8 KiB
-    constexpr int TPW = 9, K16 = 36;
+__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+    __shared__ __attribute__((aligned(16))) float red[GU_WAVES * 8 * 64];
+    constexpr int K16 = 36, TPW = K16 / GU_WAVES;
+    static_assert(TPW * GU_WAVES == K16, "waves must divide the 36 k16-tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y;
     MELLOW_BLK_EXIT(rb)
@@ -586,10 +600,12 @@ __global__ __launch_bounds__(256) void dec_gateup16_kernel(const DecArgs a, cons
         float h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float gv = (red[(0 * 8 + rbase + r) * 64 + gl] + red[(1 * 8 + rbase + r) * 64 + gl]) +
-                             (red[(2 * 8 + rbase + r) * 64 + gl] + red[(3 * 8 + rbase + r) * 64 + gl]);
-            const float uv = (red[(0 * 8 + rbase + r) * 64 + ul] + red[(1 * 8 + rbase + r) * 64 + ul]) +
-                             (red[(2 * 8 + rbase + r) * 64 + ul] + red[(3 * 8 + rbase + r) * 64 + ul]);
+            float gv = red[(rbase + r) * 64 + gl], uv = red[(rbase + r) * 64 + ul];
+#pragma unroll
+            for (int wv = 1; wv < GU_WAVES; ++wv) {                       // fixed order
+                gv += red[(wv * 8 + rbase + r) * 64 + gl];
+                uv += red[(wv * 8 + rbase + r) * 64 + ul];
+            }
             h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
         }
         // hidden unit k = 8*nt + 4*q + r: down k-tile nt, F32-layout lane' = m + 32*q
@@ -794,7 +810,7 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
     MELLOW_LAUNCH_BLK(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), a, Wp16);
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_gateup16_kernel, dim3(192, a.RB), dim3(256), a, Wp16);
+    MELLOW_LAUNCH_BLK(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), a, Wp16);
 }
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
     MELLOW_LAUNCH_BLK(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), a, Wp, K8p);
@@ -809,8 +825,8 @@ void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipSt
     }
 }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s) {
-    if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
-    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false>), dim3(vocab / 32, 1, a.RB), dim3(256), 0, s, a, Wp, K8p, a.xnF, vocab);
+    if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true>), dim3(vocab / 32, 1, a.RB), dim3(LM_WAVES * 64), 0, s, a, Wp, K8p, a.xnF, vocab);
+    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false>), dim3(vocab / 32, 1, a.RB), dim3(LM_WAVES * 64), 0, s, a, Wp, K8p, a.xnF, vocab);
 }
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
                        const LoopArgs& loop, hipStream_t s) {

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Small workload for rocprofv3 --pmc passes: encoder + prefill only (the fp32 MFMA GEMM family) at B=32."""
+"""Small workload for rocprofv3 --pmc passes: encoder + prefill only (the dense GEMM family) at B=32, in the bench's numeric
+mode (MELLOW_PRECISION, default f32x3)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mellow_amd import synth
 from mellow_amd.engine import Engine
-eng = Engine(device=0, max_positions=1024)
+eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"))
 eng.load_state_dict(synth.make_state_dict(0))
 B = 32
 a1, a2, ids = synth.make_batch(B)
