@@ -76,13 +76,18 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 //     X = baseF + sum_{s<KCD} dslabF[s]  (residual stream, un-normalised; norm weight folded into W)
 //     out: pq[kc][row][960] row-major slabs (consumer = attention, row-parallel)
 // ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_QKV_WAVES
+#define MELLOW_QKV_WAVES 9     // 9 x 1 k-tile: 53.0 vs 53.6 ms of decode per 63 steps with 3 x 3
+#endif
+constexpr int QW = MELLOW_QKV_WAVES;                 // compute waves: 3 x 3 k-tiles or 9 x 1
+constexpr int QKV_THREADS = QW * 64 < 256 ? 256 : QW * 64;
 template <int KCD, bool BLK, bool FIRST>
-__global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
-    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
-    __shared__ float ssq_s[3 * 32];
+__global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+    __shared__ __attribute__((aligned(16))) float red[QW * 16 * 64];
+    __shared__ float ssq_s[QW * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
-    constexpr int KPW = 72 / (DEC_KC_QKV * 3);   // 3 k-tiles per wave, waves 0..2 compute, wave 3 only helps the epilogue
+    constexpr int KPW = 72 / (DEC_KC_QKV * QW);   // k-tiles per compute wave (with QW = 3, wave 3 only helps the epilogue)
     // The first kernel of a step (a.first): advance the position word (nothing of the previous step reads it any more)
     // and stage this position's RoPE row at a fixed address, so that no attention kernel of the step has to chase
     // pos -> table row (two dependent round trips).  One half-wave: the loads of *d_pos precede the store in program order.
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
         if (tid == 0 && a.inc_pos) *a.d_pos = p;
     }
     MELLOW_BLK_EXIT(rb)      // every row of this block has stopped (workgroup-uniform)
-    if (wave < 3) {
-        const int k8_0 = (kc * 3 + wave) * KPW;
+    if (wave < QW) {
+        const int k8_0 = (kc * QW + wave) * KPW;
         const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
         const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
@@ -134,13 +139,22 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const DecArgs a, const flo
     }
     __syncthreads();
     if (nt == 0 && tid < 32)
-        a.ssq1[((int64_t)rb * 32 + tid) * DEC_KC_QKV + kc] = (ssq_s[tid] + ssq_s[32 + tid]) + ssq_s[64 + tid];
+    {
+        float ssum = ssq_s[tid & 31];
+#pragma unroll
+        for (int wv = 1; wv < QW; ++wv) ssum += ssq_s[wv * 32 + (tid & 31)];
+        a.ssq1[((int64_t)rb * 32 + tid) * DEC_KC_QKV + kc] = ssum;
+    }
+    if (tid >= 256) return;                              // (QW = 9 only) the epilogue is 256 threads wide; no barrier follows
     const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 4 * gq + j;
-        v[j] = (red[(0 * 16 + r) * 64 + mm + 32 * hh] + red[(1 * 16 + r) * 64 + mm + 32 * hh]) + red[(2 * 16 + r) * 64 + mm + 32 * hh];
+        float sacc = red[r * 64 + mm + 32 * hh];
+#pragma unroll
+        for (int wv = 1; wv < QW; ++wv) sacc += red[(wv * 16 + r) * 64 + mm + 32 * hh];
+        v[j] = sacc;
     }
     const int n = nt * 32 + 8 * gq + 4 * hh;
     if (n < 960)
@@ -618,9 +632,12 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
 //     X = h (SwiGLU output of K4b, F32-layout);  out: down slabs in F32-layout (next layer's qkv / final norm)
 // ----------------------------------------------------------------------------------------------------
 #ifndef MELLOW_DOWN_WAVES
-#define MELLOW_DOWN_WAVES 6
+#define MELLOW_DOWN_WAVES 4
 #endif
-constexpr int DN_WAVES = MELLOW_DOWN_WAVES;       // 6 x 4 k-tiles or 8 x 3 (two waves on every SIMD)
+// waves per workgroup: 4 x 6 k-tiles (one wave per SIMD, a 4-way LDS reduction): 52.2 ms of decode per 63 steps against
+// 53.0-53.2 with 6 x 4, 8 x 3 or 12 x 2 (same box, tools/ab_build.sh)
+constexpr int DN_WAVES = MELLOW_DOWN_WAVES;
+static_assert(DN_WAVES >= 4 && 192 % (8 * DN_WAVES) == 0, "the epilogue needs 256 threads; waves must divide the k-tiles");
 template <bool BLK>
 __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
     __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
@@ -793,8 +810,8 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
     // the first qkv launch of a step (a.first) always starts from a materialised x (kcd == 0); later ones sum the down slabs
 #define MELLOW_QKV(KCD, FIRST)                                                                              \
     do {                                                                                                    \
-        if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST>), grid, dim3(256), 0, s, a, Wp, K8p);   \
-        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST>), grid, dim3(256), 0, s, a, Wp, K8p);             \
+        if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p);   \
+        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p);             \
     } while (0)
     if (kcd == 0 && a.first) MELLOW_QKV(0, true);
     else if (kcd == 0) MELLOW_QKV(0, false);

@@ -1052,14 +1052,13 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
 // The decode attention loads whole key groups before it knows the position and masks them by WEIGHT (exp(-inf) = 0): a
 // slot beyond the context must therefore hold a finite value, or 0 x NaN poisons the row.  A fresh page is zeroed when it
 // is allocated; a reused one may hold an earlier call's appended keys -- even NaN from a poisoned request -- so the V slots
-// [T, Tmax) of every page are cleared once per prefill (one strided memset, ~0.1 GB at B = 32; K needs none: a NaN score of
-// a masked key is replaced by -inf with a select).
-static int clear_page_tails(mellow_engine* e, int T) {
+// beyond the prefix, [T, Tmax), are cleared once per prefill (one coalesced fill kernel, 80 MB at B = 32 / max_len 64: ~20 us; K needs none: a NaN score of a masked key is replaced by -inf with a select).
+static int clear_page_tails(mellow_engine* e, int T, int t_end) {
     const int Tmax = e->kv_Tmax;
-    if (T >= Tmax) return 0;
-    const size_t pitch = (size_t)Tmax * 64 * sizeof(float), width = (size_t)(Tmax - T) * 64 * sizeof(float);
-    const size_t pages = (size_t)e->cfg.num_layers * e->kv_B * 3;
-    HIPCHK(hipMemset2DAsync(e->vcache.p + (size_t)T * 64, pitch, 0, width, pages, e->stream));
+    if (t_end > Tmax) t_end = Tmax;
+    if (T >= t_end) return 0;
+    launch_clear_page_slots(e->vcache.p, (int64_t)e->cfg.num_layers * e->kv_B * 3, Tmax, T, t_end, e->stream);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1254,7 +1253,7 @@ int mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int
     HIPCHK(hipSetDevice(e->device));
     CHK(ensure_lm(e, B, T, T + reserve + 1));
     HIPCHK(hipMemcpyAsync(e->lm_x.p, prefix, (size_t)B * T * 576 * 4, hipMemcpyDeviceToDevice, e->stream));
-    CHK(clear_page_tails(e, T));
+    CHK(clear_page_tails(e, T, e->kv_Tmax));
     CHK(run_prefill(e, B, T, nullptr));
     if (logits)
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1408,7 +1407,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         HIPCHK(hipMemcpyAsync(e->d_blk_left, e->h_blk, 64 * sizeof(int32_t), hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(e->out_tok.p, 0xff, (size_t)Bp * max_len * sizeof(int32_t), s));
     }
-    CHK(clear_page_tails(e, T));
+    CHK(clear_page_tails(e, T, e->kv_Tmax));     // everything a key-group load can touch (whole chunks are loaded, then masked)
     CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, e->lm_x.p));
     HIPCHK(hipEventRecord(e->ev_phase[1], s));
     RecordArgs rec;
