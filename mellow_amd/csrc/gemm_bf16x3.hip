@@ -333,7 +333,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     const int arow = tid >> 1, akh = tid & 1;
     int am = pm * BM + arow;
     am = am < g.M ? am : g.M - 1;
-    const float* a_ptr = g.A + (int64_t)am * g.lda + akh * 8;
+    // A_FRAMES (the STFT): row m = frame (m % fpc) of clip (m / fpc), a 1024-sample window starting at hop * frame
+    const int64_t a_off = g.a_mode == A_FRAMES ? (int64_t)(am / g.fpc) * g.clip_stride + (int64_t)(am % g.fpc) * g.hop : (int64_t)am * g.lda;
+    const float* a_ptr = g.A + a_off + akh * 8;
     const int a_lds = (arow >> 5) * 64 + (arow & 31) + 32 * akh;            // + piece * 256
     const i32x4* w_ptr[3];
     int w_lds[3];
@@ -488,6 +490,8 @@ void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s) {
         case EPI_LINEAR: launchbf<EPI_LINEAR>(a, s); break;
         case EPI_SWIGLU: launchbf<EPI_SWIGLU>(a, s); break;
         case EPI_QKV_ROPE: launchbf<EPI_QKV_ROPE>(a, s); break;
+        case EPI_POWER: launchbf<EPI_POWER>(a, s); break;       // A_FRAMES only through the pipelined kernel (K = 1024)
+        case EPI_LOGMEL: launchbf<EPI_LOGMEL>(a, s); break;
         default: break;
     }
 }
