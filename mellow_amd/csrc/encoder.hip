@@ -2,6 +2,8 @@
 // index-math kernels: permutations of the reference (reflect pad, bicubic resample + 4x256 fold,
 // cyclic shift + window partition, patch-merging gather, un-fold for the token-semantic head) are
 // address arithmetic on loads, never materialised copies.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -307,11 +309,139 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
             *reinterpret_cast<float4*>(dst + v * 4) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
     }
 }
+// ---- the same on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32) -------------------------------------------------
+// One wave per (window, head).  Scores are computed TRANSPOSED, S^T[key][query] = sum_d K[key][d] Q[query][d] (K tile = MFMA A
+// operand, Q = B operand), so a lane owns ONE query column and 16 keys of each 32-key tile: the softmax over the 64 keys of a
+// query is in-lane plus one half-wave exchange, and the P^T accumulator registers are directly the B operand of
+// O^T[d][query] += V^T[d][key] P^T[key][query] (k-step r pairs the keys the two half-waves hold in register r) -- the scheme of
+// prefill_attn.hip, without the causal mask, with the relative-position bias and the shift mask added to S.
+//   * head_dim 24: k-step s of the QK^T product uses d = s + 12 h (h = lane / 32), so a lane's operand values are 12 contiguous
+//     floats of its q / k row (3 float4 loads each, straight from global memory: no LDS for Q or K);
+//   * V^T operand: V[key][d = lane % 32] from a row-major LDS copy of the wave's 64 x 24 V tile (lanes 24..31 multiply zeros:
+//     the 32-row output tile is 25 % padding);  48 + 64 = 112 MFMAs per tile instead of 3072 FMAs + 768 LDS broadcasts per lane.
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                    int C, int nH, const float* __restrict__ bias_exp,
+                                                                    const float* __restrict__ mask, int nW,
+                                                                    int64_t n_tiles) {
+    __shared__ __attribute__((aligned(16))) float Vs[4][64 * 24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;   // tile = window * nH + head
+    const bool active = tile < n_tiles;
+    const int64_t win = active ? tile / nH : 0;
+    const int hd = active ? (int)(tile % nH) : 0;
+    const int h = lane >> 5, ml = lane & 31;
+    const float scale = 0.20412414523193150818f;            // 24^-0.5 (python float -> fp32 scalar multiply)
+    // operands of S^T: token rows ml and ml + 32, d = 12 h .. 12 h + 11
+    float kf[2][12], qf[2][12];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* row = qkv + (win * 64 + t * 32 + ml) * (3 * C) + hd * 24 + 12 * h;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const float4 q4 = *reinterpret_cast<const float4*>(row + v * 4);
+            const float4 k4 = *reinterpret_cast<const float4*>(row + C + v * 4);
+            qf[t][4 * v] = q4.x * scale; qf[t][4 * v + 1] = q4.y * scale; qf[t][4 * v + 2] = q4.z * scale; qf[t][4 * v + 3] = q4.w * scale;
+            kf[t][4 * v] = k4.x; kf[t][4 * v + 1] = k4.y; kf[t][4 * v + 2] = k4.z; kf[t][4 * v + 3] = k4.w;
+        }
+    }
+    {   // V tile of this wave -> LDS, row-major [key][24]
+        const float* vrow = qkv + (win * 64 + lane) * (3 * C) + 2 * C + hd * 24;
+#pragma unroll
+        for (int v = 0; v < 6; ++v)
+            *reinterpret_cast<float4*>(&Vs[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(vrow + v * 4);
+    }
+    // S^T tiles [key tile kt][query tile qt]
+    f32x16 S[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[kt][qt][r] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < 12; ++s_) S[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][s_], qf[qt][s_], S[kt][qt], 0, 0, 0);
+        }
+    // lane: query qt*32 + ml, keys kt*32 + (r&3) + 8(r>>2) + 4h.  bias / mask rows are [query][key]: 4 consecutive keys per float4
+    float inv[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = qt * 32 + ml;
+        const float* brow = bias_exp + ((int64_t)hd * 64 + qi) * 64;
+        const float* mrow = mask ? mask + ((win % nW) * 64 + qi) * 64 : nullptr;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int k0 = kt * 32 + 8 * g4 + 4 * h;
+                const float4 b4 = *reinterpret_cast<const float4*>(brow + k0);
+                float add[4] = {b4.x, b4.y, b4.z, b4.w};
+                if (mrow) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mrow + k0);
+                    // (s + bias) + mask: the reference's order (htsat.py:317, 321)
+                    S[kt][qt][4 * g4 + 0] = (S[kt][qt][4 * g4 + 0] + add[0]) + m4.x;
+                    S[kt][qt][4 * g4 + 1] = (S[kt][qt][4 * g4 + 1] + add[1]) + m4.y;
+                    S[kt][qt][4 * g4 + 2] = (S[kt][qt][4 * g4 + 2] + add[2]) + m4.z;
+                    S[kt][qt][4 * g4 + 3] = (S[kt][qt][4 * g4 + 3] + add[3]) + m4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S[kt][qt][4 * g4 + j] += add[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, S[kt][qt][4 * g4 + j]);
+            }
+        mx = half_max(mx);                                   // the other 32 keys of this query live in lane ^ 32
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f((S[kt][qt][r] - mx) * 1.44269504088896340736f);
+                S[kt][qt][r] = pv;
+                sum += pv;
+            }
+        inv[qt] = 1.0f / half_sum(sum);
+    }
+    __syncthreads();                                         // V tiles staged (each wave reads only its own)
+    // O^T[d][query] += V^T[d][key] P^T[key][query]
+    f32x16 O[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[qt][r] = 0.f;
+    const float* Vc = Vs[wave];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float a = ml < 24 ? Vc[key * 24 + ml] : 0.f;
+            O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[kt][0][r], O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[kt][1][r], O[1], 0, 0, 0);
+        }
+    if (active) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float* dst = out + (win * 64 + qt * 32 + ml) * C + hd * 24;
+#pragma unroll
+            for (int g4 = 0; g4 < 3; ++g4) {                 // d = 8 g4 + 4 h + (0..3) < 24
+                const int d = 8 * g4 + 4 * h;
+                *reinterpret_cast<float4*>(dst + d) = make_float4(O[qt][4 * g4] * inv[qt], O[qt][4 * g4 + 1] * inv[qt],
+                                                                  O[qt][4 * g4 + 2] * inv[qt], O[qt][4 * g4 + 3] * inv[qt]);
+            }
+        }
+    }
+}
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
                              const float* mask, int nW, hipStream_t s) {
     const int64_t n_tiles = (int64_t)(M / 64) * nH;
-    hipLaunchKernelGGL(window_attention_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
-                       bias_exp, mask, nW, n_tiles);
+    static const bool valu = getenv("MELLOW_WINATTN_VALU") != nullptr;     // developer A/B: the VALU kernel above
+    if (valu)
+        hipLaunchKernelGGL(window_attention_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+                           bias_exp, mask, nW, n_tiles);
+    else
+        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+                           bias_exp, mask, nW, n_tiles);
 }
 
 // ---- A10 tail: latent mean + im2col for the token-semantic conv (htsat.py:742-775) ---------------------------
