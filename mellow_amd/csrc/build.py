@@ -44,7 +44,7 @@ def _stale(target, deps):
 # loop iteration (v_accvgpr_read/write: as many VALU issue slots as the MFMAs themselves), and every `O *= alpha` of the
 # flash attention is a read-modify-write through copies.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-FILE_FLAGS = {name: VGPR_FORM for name in os.environ.get("MELLOW_VGPR_FORM_FILES", "gemm_bf16x3.hip gemm_fp8.hip prefill_attn.hip").split()}
+FILE_FLAGS = {name: VGPR_FORM for name in os.environ.get("MELLOW_VGPR_FORM_FILES", "gemm_bf16x3.hip gemm_fp8.hip prefill_attn.hip encoder.hip").split()}
 
 
 def build(force=False, verbose=False):
