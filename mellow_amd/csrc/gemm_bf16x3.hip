@@ -403,6 +403,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
         if (i_ >= 19 && i_ < 24) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              \
     }
 
+    // the wave raises its priority for the MFMA burst so that the SIMD's other wave does not steal issue slots in the middle
+    // of it (LM shapes +1..5 %, tools/ab_build.sh -DMELLOW_X3_NO_SETPRIO for the A/B)
+#ifdef MELLOW_X3_NO_SETPRIO
+#define X3_PRIO(P)
+#else
+#define X3_PRIO(P) __builtin_amdgcn_s_setprio(P);
+#endif
     i32x4 fa0[2][3], fw0[2][3], fa1[2][3], fw1[2][3];
     X3_GLOAD(0, raA, rwA)
     X3_GLOAD(1, raB, rwB)
@@ -417,11 +424,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     // t+4 -> the same registers (two sets alternate); barrier.  Unrolled by 6: stage indices and register sets are static.
 #define X3_ITER(T, SN, SW, FA, FW, FAN, FWN, ra, rw)                                             \
     if ((T) < KT) {                                                                              \
+        X3_PRIO(2)                                                                               \
         X3_FRAGS(SN, FAN, FWN)                                                                   \
         X3_MFMAS(FA, FW)                                                                         \
         X3_LSTORE(SW, ra, rw)                                                                    \
         X3_GLOAD((T) + 4, ra, rw)                                                                \
         X3_SCHED()                                                                               \
+        X3_PRIO(0)                                                                               \
         __syncthreads();                                                                         \
     }
     for (int kt = 0; kt < KT; kt += 6) {
@@ -439,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
 #undef X3_MFMAS
 #undef X3_SCHED
 #undef X3_ITER
+#undef X3_PRIO
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
 
