@@ -85,7 +85,10 @@ double gemm_flops(const GemmArgs& a);
 // split factors are compile-time so that partial-sum ("slab") loads are fully unrolled and issued together
 constexpr int DEC_KC_QKV = 8;    // qkv: 72 k-tiles = 8 chunks x 3 waves x 3  (30 x 8 = 240 workgroups <= 256 CUs)
 constexpr int DEC_KC_DOWN = 8;   // down: 192 k-tiles = 8 chunks x 6 waves x 4
-constexpr int DEC_TS = 2;        // key splits of the decode attention, merged by the o_proj prologue
+#ifndef MELLOW_DEC_TS
+#define MELLOW_DEC_TS 2
+#endif
+constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention, merged by the o_proj prologue
 struct DecArgs {
     int rows = 0, RB = 0;          // padded batch rows (multiple of 32), row blocks
     int Tmax = 0;

@@ -553,7 +553,7 @@ def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     """precision="fp8": e4m3 GEMMs in the Swin linears and LM prefill, everything else fp32.  Not bit-exact by design;
     the test pins (a) determinism, (b) bounded error against the fp32 engine, (c) that the fp32 engine is untouched.
     Measured on the synthetic (random-weight, un-trained) checkpoint: prefix rel-rms 5e-2, prefill logits rel-rms 0.17,
-    first-token agreement ~0.6 -- a random network amplifies 3-bit-mantissa noise; see DESIGN.md §9."""
+    first-token agreement ~0.6 -- a random network amplifies 3-bit-mantissa noise; see DESIGN.md §6b."""
     from mellow_amd.engine import Engine
     e8 = Engine(device=0, precision="fp8")
     e8.load_state_dict(synth_sd)
@@ -562,17 +562,19 @@ def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     p32 = engine_f32.prefix(a1, a2, ids)
     p8 = e8.prefix(a1, a2, ids)
     rel = float((p8 - p32).pow(2).mean().sqrt() / p32.pow(2).mean().sqrt())
-    assert torch.isfinite(p8).all() and 1e-4 < rel < 0.15, rel
+    # error model: one e4m3 GEMM costs ~4e-2 of max (3-bit mantissa, per-row / per-channel scales); the encoder chains ~50 of
+    # them with LayerNorms in between and lands at 4.9e-2 rel-rms on this checkpoint: bounds at 1.6x the measured values
+    assert torch.isfinite(p8).all() and 1e-3 < rel < 0.08, rel
     l32 = engine_f32.lm_prefill(p32, reserve=2).cpu()
     l8 = e8.lm_prefill(p32, reserve=2).cpu()
     rel_l = float((l8 - l32).pow(2).mean().sqrt() / l32.pow(2).mean().sqrt())
-    assert torch.isfinite(l8).all() and rel_l < 0.5, rel_l
+    assert torch.isfinite(l8).all() and 1e-3 < rel_l < 0.27, rel_l       # measured 0.165 (30 layers x 4 fp8 GEMMs)
     t8a, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     t8b, *_ = e8.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     assert np.array_equal(t8a, t8b)                                      # deterministic
     t32, *_ = engine_f32.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     agree = float((t8a[:, 0] == t32[:, 0]).mean())
-    assert agree >= 0.25, agree                                          # far above chance (1/49152)
+    assert agree >= 0.44, agree                                          # measured 0.59-0.66 of 16 rows; chance is 1/49152
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
     # config 5's batch (128, max_len 64): per-row quantisation keeps rows batch-independent, so the first 16 rows of the
