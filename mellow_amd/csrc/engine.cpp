@@ -172,6 +172,7 @@ struct mellow_engine {
     // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
     bool fp8 = false;
     int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
+    bool decode_only_weight = false;             // set while packing weights only the decode kernels read: no bf16x3 / fp8 copy
     std::unordered_map<const float*, void*> bf_w;   // fp32 packed pointer -> PB copy
     struct Fp8W { uint8_t* w8; float* scale; };
     std::unordered_map<const float*, Fp8W> fp8_w;
@@ -515,7 +516,7 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(d0));
     if (d1) HIPCHK(hipFree(d1));
-    if (e->f32x3_terms && p.KP % 16 == 0) {
+    if (e->f32x3_terms && p.KP % 16 == 0 && !e->decode_only_weight) {
         float* pb = nullptr;
         CHK(dev_alloc(e, &pb, ((size_t)p.NP * p.KP * 6 + 3) / 4));
         launch_pack_bf16x3(p.p, p.NP, p.KP, pb, e->stream);
@@ -523,7 +524,7 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
         HIPCHK(hipStreamSynchronize(e->stream));
         e->bf_w[p.p] = pb;
     }
-    if (e->fp8 && p.KP % 64 == 0) {
+    if (e->fp8 && p.KP % 64 == 0 && !e->decode_only_weight) {
         float *w8f = nullptr, *sc = nullptr;
         CHK(dev_alloc(e, &w8f, ((size_t)p.NP * p.KP + 3) / 4));
         CHK(dev_alloc(e, &sc, (size_t)p.NP));
@@ -687,7 +688,9 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         const std::string k = L + "model.embed_tokens.weight";
         CHK(expect_shape(get(e, k), k, {V, H}));
         CHK(upload(e, &e->embed, get(e, k)->f(), (size_t)V * H));
+        e->decode_only_weight = true;                 // the lm_head runs in the decode kernels only (last position)
         CHK(make_packed(e, get(e, k)->f(), nullptr, V, H, &e->lm_head));
+        e->decode_only_weight = false;
     }
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const std::string p = L + "model.layers." + std::to_string(l) + ".";
@@ -715,7 +718,9 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
             std::vector<float> f(qkv);
             for (int n = 0; n < 960; ++n)
                 for (int kk = 0; kk < H; ++kk) f[(size_t)n * H + kk] = qkv[(size_t)n * H + kk] * l1->f()[kk];
+            e->decode_only_weight = true;
             CHK(make_packed(e, f.data(), nullptr, 960, H, &w.qkv_f));
+            e->decode_only_weight = false;
             std::vector<float> gf((size_t)I * H), uf((size_t)I * H);
             for (int n = 0; n < I; ++n)
                 for (int kk = 0; kk < H; ++kk) {
