@@ -260,6 +260,8 @@ class MellowWrapper:
             text_prompts.append(tp)
         rank, world = self._dp()
         n = len(examples)
+        if n == 0:          # the reference fails in torch.cat(audio_tensors) (wrapper.py:178) on an empty list
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         lo, hi = 0, n
         if world > 1:
             from .dist import shard_range

@@ -234,15 +234,14 @@ def test_multi_row_block_batch(engine):
     assert np.array_equal(t40[:3], t_lo) and np.array_equal(t40[35:40], t_hi)
 
 
-def test_long_context_decode_matches_independent_prefill(engine, golden_dir):
-    """Contexts beyond one attention chunk (> 448 keys) and the KV-cached decode as a whole, checked against an
-    independent implementation inside the engine: the prefill path (big GEMM + flash attention) run on the
-    EXTENDED sequence must give the same last-position logits as the step-by-step decode path."""
+@pytest.mark.parametrize("B,n_new", [(2, 90), (1, 1600)])
+def test_long_context_decode_matches_independent_prefill(engine, golden_dir, B, n_new):
+    """Contexts beyond one attention chunk (> 448 keys) up to the engine's 2048-key limit (389 + 1600 = 1989 keys: five key
+    chunks per split), checked against an independent implementation inside the engine: the prefill path (big GEMM + flash
+    attention) run on the EXTENDED sequence must give the same last-position logits as the step-by-step KV-cached decode.
+    (Up to 688 keys the decode is pinned against the reference itself: test_late_positions_match_reference.)"""
     e = np.load(os.path.join(golden_dir, "enc10.npz"))
-    prefix = torch.from_numpy(e["prefix"])                       # (2, 389, 576)
-    B, T0 = prefix.shape[0], prefix.shape[1]
-    n_new = 90                                                   # 389 + 90 = 479 keys > 448
-    embed = None
+    prefix = torch.from_numpy(e["prefix"])[:B]                   # (B, 389, 576)
     logits = engine.lm_prefill(prefix, reserve=n_new + 2)
     toks = []
     for i in range(n_new):
@@ -253,10 +252,25 @@ def test_long_context_decode_matches_independent_prefill(engine, golden_dir):
     toks = torch.stack(toks, 1).long()                           # (B, n_new)
     from mellow_amd import spec as _s
     sd_embed = synth.make_state_dict(0)[_s.LM + "model.embed_tokens.weight"]
-    ext = torch.cat((prefix, sd_embed[toks]), 1)                 # (B, 479, 576)
+    ext = torch.cat((prefix, sd_embed[toks]), 1)                 # (B, 389 + n_new, 576)
     pre_logits = engine.lm_prefill(ext, reserve=2).cpu()
-    _close(dec_logits, pre_logits, rel=0, atol=3e-3, name="decode@479 vs prefill of the extended sequence")
+    _close(dec_logits, pre_logits, rel=0, atol=3e-3, name=f"decode@{389 + n_new} vs prefill of the extended sequence")
     assert dec_logits.argmax(-1).tolist() == pre_logits.argmax(-1).tolist()
+
+
+def test_max_len_at_the_key_limit(engine_f32, batch2, golden_dir):
+    """max_len = everything the KV pages can hold (2048 - 389 = 1659 steps): runs to the end, starts with the golden tokens,
+    and a longer request is refused by the C ABI (the wrapper clamps with a warning instead: tests/test_tokenizer_cpu.py)."""
+    from mellow_amd.engine import EngineError
+    a1, a2, ids = batch2
+    L = engine_f32.max_new_tokens_limit()
+    assert L == 2048 - spec.PREFIX_LEN
+    toks, lens, n, _ = engine_f32.generate(a1[:1], a2[:1], ids[:1], max_len=L, stop_id=-1)
+    g = np.load(os.path.join(golden_dir, "late.npz"))
+    assert n == L and toks.shape == (1, L) and np.array_equal(toks[0, :300], g["tokens"][0])
+    assert (toks >= 0).all() and (toks < 49152).all()
+    with pytest.raises(EngineError, match="2048-key"):
+        engine_f32.generate(a1[:1], a2[:1], ids[:1], max_len=L + 1, stop_id=-1)
 
 
 def test_late_positions_match_reference(engine, batch2, golden_dir):

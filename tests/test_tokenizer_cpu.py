@@ -112,3 +112,12 @@ def test_detokenise_and_cut_at_first_stop(bpe):
     with pytest.warns(UserWarning, match="clamped"):
         w._generate_batch(torch.zeros(2, 8), torch.zeros(2, 8), ids, entry_length=10000)
     assert eng.calls[-1][1] == 2048 - spec.PREFIX_LEN
+
+
+def test_empty_example_list_fails_like_the_reference(bpe):
+    """`generate([])`: the reference dies in `torch.cat(audio_tensors)` (wrapper.py:178); same exception type and message here."""
+    w = _wrapper(bpe, _FakeEngine(np.zeros((0, 0), np.int32), np.zeros((0,), np.int32), 0))
+    with pytest.raises(RuntimeError, match="non-empty list"):
+        w.generate(examples=[], max_len=8, top_p=0.8, temperature=1.0)
+    with pytest.raises(ValueError):                      # malformed example: unpacking error, like wrapper.py:272
+        w.generate(examples=[["a.wav", "b.wav"]], max_len=8, top_p=0.8, temperature=1.0)
