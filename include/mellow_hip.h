@@ -121,6 +121,13 @@ int  mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, in
 /* A15 decode step: append embed_tokens(token_ids) (wrapper.py:237) at the next position and return the
  * new last-position logits.  token_ids dev i32 [B]; logits dev [B][vocab] (may be NULL). */
 int  mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* logits);
+/* lm.model.embed_tokens(ids) (decoder.py:47,64-66; wrapper.py:237): token_ids dev i32 [n] -> out dev [n][hidden]. */
+int  mellow_embed_tokens(mellow_engine_t* e, const int32_t* token_ids, int n, float* out);
+/* The decoder's forward over a whole embedded sequence, `self.lm(inputs_embeds=embedding_cat).logits` of the training-time
+ * forward (Mellow.forward mellow.py:89-98 -> DecoderModel.forward decoder.py:57-90, which concatenates the prefix with the
+ * embedded answer tokens): embeds dev [B][T][hidden] -> logits dev [B][T - from_pos][vocab], the rows of positions
+ * t >= from_pos.  Inference arithmetic only (no loss, no gradient); leaves no decode state behind. */
+int  mellow_lm_forward_logits(mellow_engine_t* e, const float* embeds, int B, int T, int from_pos, float* logits);
 /* A0 (host harness of the reference, wrapper.py:146 `torchaudio.transforms.Resample(sr, 32000)`) on the device:
  * sinc-interpolation resampling with a Hann window, lowpass_filter_width 6, rolloff 0.99, gcd-reduced polyphase bank.
  * wav dev [n][n_in] -> out dev [n][*n_out], *n_out = ceil(new_freq * n_in / orig_freq); out == NULL only queries *n_out. */

@@ -576,6 +576,25 @@ __global__ __launch_bounds__(192) void downsample33_kernel(const float* __restri
     for (int c = threadIdx.x; c < 576; c += 192)
         out[((int64_t)clip * 129 + r) * 576 + c] = audio_row_value(proj33 + (int64_t)clip * 33 * 576, r, c);
 }
+__global__ __launch_bounds__(192) void gather_rows_kernel(const float* __restrict__ table, int width4, const int32_t* __restrict__ ids,
+                                                          int n_rows, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int64_t src = min(max(ids[i], 0), n_rows - 1);
+    for (int c = threadIdx.x; c < width4; c += 192)
+        reinterpret_cast<float4*>(out)[(int64_t)i * width4 + c] = reinterpret_cast<const float4*>(table)[src * width4 + c];
+}
+void launch_gather_rows(const float* table, int width, const int32_t* ids, int n, int n_rows, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(192), 0, s, table, width / 4, ids, n_rows, out);
+}
+__global__ __launch_bounds__(192) void gather_span_kernel(const float* __restrict__ in, int T, int from_pos, int n, float* __restrict__ out) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x < 144)
+        reinterpret_cast<float4*>(out)[((int64_t)b * n + j) * 144 + threadIdx.x] =
+            reinterpret_cast<const float4*>(in)[((int64_t)b * T + from_pos + j) * 144 + threadIdx.x];
+}
+void launch_gather_span(const float* in, int B, int T, int from_pos, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_span_kernel, dim3(n, B), dim3(192), 0, s, in, T, from_pos, n, out);
+}
 // zero the slots [t0, t1) of every KV page (pages x Tmax x 64 floats): plain coalesced float4 stores
 __global__ __launch_bounds__(256) void clear_page_slots_kernel(float* __restrict__ cache, int64_t pages, int Tmax, int t0, int t1) {
     const int64_t per = (int64_t)(t1 - t0) * 16;                   // float4 per page

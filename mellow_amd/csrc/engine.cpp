@@ -1099,7 +1099,7 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
 }
 
 static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, bool inc_pos);
-static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
+static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_positions = false) {
     hipStream_t s = e->stream;
     const int M = B * T, Tmax = e->kv_Tmax;
     const int NL = e->cfg.num_layers;
@@ -1118,7 +1118,7 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
         }
         // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
         // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
-        if (l == NL - 1) break;
+        if (l == NL - 1 && !all_positions) break;
         {
             // causal QK^T + PV: 4*64 flops per (query,key) pair per head
             ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
@@ -1141,6 +1141,10 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec) {
             g.resid = x; g.ldr = 576;
             CHK(run_gemm(e, g));
         }
+    }
+    if (all_positions) {        // x = the hidden states after all layers, every position (mellow_lm_forward_logits)
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     // x now holds the input of the last layer.  Position word = index of the LAST prefix token: the decode kernels
     // treat it as "the new token" (keys 0..T-2 from the pages, key T-1 recomputed and re-appended), and the first
@@ -1285,6 +1289,42 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// lm.model.embed_tokens(ids) (reference decoder.py:47,64-66; wrapper.py:237): rows of the embedding table
+int mellow_embed_tokens(mellow_engine_t* e, const int32_t* token_ids, int n, float* out) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!token_ids || !out || n <= 0) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    launch_gather_rows(e->embed, 576, token_ids, n, e->cfg.vocab_size, out, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// The decoder's forward over a whole embedded sequence (reference decoder.py:57-90 `self.lm(inputs_embeds=embedding_cat)`,
+// reached from Mellow.forward mellow.py:89-98 -- the training-time forward): logits of EVERY position t >= from_pos, not only
+// the last one.  embeds dev [B][T][hidden]; logits dev [B][T - from_pos][vocab].  All 30 layers run on all positions (the
+// generation path's last-layer shortcut does not apply), then the final RMSNorm and the tied lm_head as one GEMM on the
+// exact fp32 kernel (in every precision mode: the head is not part of the split / fp8 GEMM set).
+int mellow_lm_forward_logits(mellow_engine_t* e, const float* embeds, int B, int T, int from_pos, float* logits) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!embeds || !logits || B <= 0 || T <= 0 || from_pos < 0 || from_pos >= T) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    CHK(ensure_lm(e, B, T, T + 1));
+    HIPCHK(hipMemcpyAsync(e->lm_x.p, embeds, (size_t)B * T * 576 * 4, hipMemcpyDeviceToDevice, s));
+    CHK(run_prefill(e, B, T, nullptr, true));
+    e->cur_B = 0;                                   // no decode state: a decode step needs a real prefill first
+    const int n = T - from_pos;
+    // final norm on the selected rows only: gather [B][n][576] out of [B][T][576] into lm_xn, then normalise in place
+    launch_gather_span(e->lm_x.p, B, T, from_pos, n, e->lm_o.p, s);
+    launch_rmsnorm(e->lm_o.p, e->lm_xn.p, B * n, 576, e->final_norm, e->cfg.rms_norm_eps, s);
+    GemmArgs g = lin(e->lm_xn.p, 576, B * n, e->lm_head, logits, e->cfg.vocab_size, nullptr);
+    launch_gemm(g, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 

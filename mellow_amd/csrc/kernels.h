@@ -193,6 +193,10 @@ void launch_gelu(const float* in, float* out, int64_t n, hipStream_t s);
 // prefix [B][389][576] from proj33 [2B][33][576] (clips 0..B-1 = audio1, B..2B-1 = audio2)
 void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
                             int sep_id, int vocab, float* prefix, hipStream_t s);
+// out[i] = table[ids[i]] (rows of `width` floats, width % 4 == 0; ids clamped to [0, n_rows))
+void launch_gather_rows(const float* table, int width, const int32_t* ids, int n, int n_rows, float* out, hipStream_t s);
+// out [B][n][576] = in [B][T][576] rows from_pos .. from_pos + n - 1
+void launch_gather_span(const float* in, int B, int T, int from_pos, int n, float* out, hipStream_t s);
 // zero the token slots [t0, t1) of `pages` KV pages of Tmax x 64 floats each
 void launch_clear_page_slots(float* cache, int64_t pages, int Tmax, int t0, int t1, hipStream_t s);
 // audio129 [n][129][576] from proj33 [n][33][576] (tap / mellow_encode)

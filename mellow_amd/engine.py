@@ -70,6 +70,8 @@ def load_library(path: Optional[str] = None):
         "mellow_lm_prefill": (ci, [vp, vp, ci, ci, ci, vp]),
         "mellow_lm_decode_step": (ci, [vp, vp, vp]),
         "mellow_argmax": (ci, [vp, vp, ci, vp]),
+        "mellow_embed_tokens": (ci, [vp, vp, ci, vp]),
+        "mellow_lm_forward_logits": (ci, [vp, vp, ci, ci, ci, vp]),
         "mellow_resample": (ci, [vp, vp, ci, i64, ci, ci, vp, i64, P(i64)]),
         "mellow_debug_enable_taps": (ci, [vp, ci]),
         "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
@@ -102,7 +104,7 @@ EXPORTED_SYMBOLS = (
     "mellow_abi_version", "mellow_last_error", "mellow_device_count", "mellow_engine_create",
     "mellow_engine_destroy", "mellow_engine_load_tensor", "mellow_engine_finalize",
     "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
-    "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax",
+    "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued",
     "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
@@ -290,6 +292,45 @@ class Engine:
         self._sync_inputs()
         self._chk(self.lib.mellow_lm_decode_step(self.h, _ptr(t), _ptr(out)))
         return out
+
+    def embed_tokens(self, token_ids) -> torch.Tensor:
+        """`lm.model.embed_tokens(ids)` (reference decoder.py:47, wrapper.py:237): (...,) ids -> (..., hidden) on the device"""
+        t = self._ids(token_ids)
+        out = torch.empty(tuple(t.shape) + (self.lm.hidden_size,), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
+        self._chk(self.lib.mellow_embed_tokens(self.h, _ptr(t), t.numel(), _ptr(out)))
+        return out
+
+    def lm_forward_logits(self, embeds, from_pos: int = 0) -> torch.Tensor:
+        """`lm(inputs_embeds=embeds).logits[:, from_pos:]` (reference decoder.py:89): (B, T, hidden) -> (B, T - from_pos, vocab)"""
+        p = self._f32(embeds)
+        B, T, H = p.shape
+        out = torch.empty((B, T - int(from_pos), self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._sync_inputs()
+        self._chk(self.lib.mellow_lm_forward_logits(self.h, _ptr(p), B, T, int(from_pos), _ptr(out)))
+        return out
+
+    def forward(self, audio1, audio2, input_ids, answer_ids, from_pos: int = 0) -> torch.Tensor:
+        """The training-time forward of the reference as inference arithmetic (`Mellow.forward`, mellow.py:89-98): logits of
+        the sequence [audio1 | sep | audio2 | sep | prompt | answer] at every position >= from_pos.  The reference returns the
+        HF output object; `.logits` of it is what this returns (no labels, no loss: decoder.py:84-89 passes labels=None)."""
+        prefix = self.prefix(audio1, audio2, input_ids)
+        ans = self.embed_tokens(answer_ids)
+        return self.lm_forward_logits(torch.cat((prefix, ans), 1), from_pos)
+
+    # -- the reference model object's call surface (wrapper.model is an nn.Module there: mellow.py:70-109) -------------------
+    def generate_prefix_inference(self, input_dict):
+        """`Mellow.generate_prefix_inference(input_dict)` (mellow.py:100-109): (prefix, None, None) -- the reference's second
+        and third values are the encoder's output dicts, which the generation path never reads (wrapper.py:233)"""
+        return self.prefix(input_dict["audio1"], input_dict["audio2"], input_dict["input"]["input_ids"]), None, None
+
+    def __call__(self, input_dict):
+        """`model(input_dict)` (mellow.py:89-98): an object whose `.logits` is (B, prefix + answer, vocab), like the HF
+        CausalLMOutput the reference returns with labels=None (decoder.py:89: loss is None)"""
+        from types import SimpleNamespace
+        logits = self.forward(input_dict["audio1"], input_dict["audio2"], input_dict["input"]["input_ids"],
+                              input_dict["answer"]["input_ids"])
+        return SimpleNamespace(logits=logits, loss=None)
 
     def argmax(self, logits) -> torch.Tensor:
         l = self._f32(logits)

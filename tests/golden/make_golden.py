@@ -198,6 +198,29 @@ def late_case(args, model, prefix, t0):
     )
 
 
+FWD_ANSWER_LEN = 12
+FWD_FROM = 380
+
+
+def forward_case(args, model, a1t, a2t, idst, prefix, t0):
+    """The training-time forward (mellow.py:89-98 -> decoder.py:57-90): `model(input_dict).logits` over the sequence
+    [prefix | embed(answer)] -- every position's logits, kept for positions >= FWD_FROM on the sub-vocabulary."""
+    g = torch.Generator().manual_seed(SEED + 77)
+    ans = torch.randint(0, 49152, (idst.shape[0], FWD_ANSWER_LEN), generator=g)
+    with torch.no_grad():
+        out = model({"audio1": a1t, "audio2": a2t, "input": {"input_ids": idst}, "answer": {"input_ids": ans}})
+        emb = model.caption_decoder.lm.model.embed_tokens(ans)
+        direct = model.caption_decoder.lm(inputs_embeds=torch.cat((prefix, emb), 1)).logits
+    logits = out.logits
+    assert logits.shape == (idst.shape[0], prefix.shape[1] + FWD_ANSWER_LEN, 49152)
+    assert torch.equal(logits, direct)
+    tail = logits[:, FWD_FROM:]
+    print(f"forward: logits {tuple(logits.shape)}, |max| {float(tail.abs().max()):.3f} ({time.time() - t0:.1f}s)")
+    np.savez_compressed(os.path.join(args.out, "forward.npz"), answer_ids=ans.numpy(), from_pos=FWD_FROM, sub_vocab=SUB_VOCAB,
+                        logits_sub=tail[:, :, SUB_VOCAB].numpy(), logits_max=tail.max(-1).values.numpy(),
+                        argmax=tail.argmax(-1).numpy(), answer_embed_sub=emb[:, :, ::9].numpy())
+
+
 def _examples(idx):
     return synth.make_examples(idx)
 
@@ -250,7 +273,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -343,6 +366,8 @@ def main():
         long30_case(args, model, sd)
     if want("late"):
         late_case(args, model, prefix, t0)
+    if want("forward"):
+        forward_case(args, model, a1t, a2t, idst, prefix, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
     print(f"done ({time.time() - t0:.1f}s)")

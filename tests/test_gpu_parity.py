@@ -299,6 +299,57 @@ def test_late_positions_match_reference(engine, batch2, golden_dir):
             assert logits.argmax(-1).cpu().tolist() == ref[:, i].tolist()
 
 
+def test_all_position_forward_matches_reference(engine, batch2, golden_dir):
+    """`Mellow.forward` (mellow.py:89-98 -> decoder.py:57-90, the training-time forward, inference arithmetic only): logits of
+    EVERY position of [prefix | embed(answer)] against the reference's own `model(input_dict).logits` (tests/golden/forward.npz),
+    through `mellow_embed_tokens` + `mellow_lm_forward_logits`; and consistency with the generation path (the last-position
+    logits of prefill are the row T-1 of the same forward)."""
+    a1, a2, ids = batch2
+    g = np.load(os.path.join(golden_dir, "forward.npz"))
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    ans, f0 = g["answer_ids"], int(g["from_pos"])
+    emb = engine.embed_tokens(ans)
+    assert emb.shape == (2, ans.shape[1], 576)
+    assert np.array_equal(emb[:, :, ::9].cpu().numpy(), g["answer_embed_sub"])          # a gather: bit-exact
+    sub = torch.from_numpy(g["sub_vocab"])
+    # (a) from the reference's prefix: isolates the LM
+    seq = torch.cat((torch.from_numpy(e["prefix"]).to(emb.device), emb), 1)
+    tail = engine.lm_forward_logits(seq, from_pos=f0)
+    assert tail.shape == (2, seq.shape[1] - f0, 49152)
+    _close(tail[:, :, sub], g["logits_sub"], rel=0, atol=3e-3, name="all-position logits (sub-vocabulary)")
+    _close(tail.max(-1).values, g["logits_max"], rel=0, atol=3e-3, name="all-position max logit")
+    assert np.array_equal(tail.argmax(-1).cpu().numpy(), g["argmax"])
+    # (b) end to end from the waveforms, like the reference's forward(input_dict)
+    tail2 = engine.forward(a1, a2, ids, ans, from_pos=f0)
+    _close(tail2[:, :, sub], g["logits_sub"], rel=0, atol=3e-3, name="forward(input_dict) logits")
+    # (c) from_pos = 0 returns every row; row T-1 of a prefix-only forward is what prefill hands to the decode loop
+    pre = torch.from_numpy(e["prefix"])
+    full = engine.lm_forward_logits(pre[:1], from_pos=0)
+    assert full.shape == (1, 389, 49152)
+    last = engine.lm_prefill(pre[:1])
+    _close(full[:, -1], last, rel=0, atol=2e-3, name="row T-1 vs prefill logits")
+    # (d) the all-position forward leaves no decode state behind, and does not disturb a later generate
+    from mellow_amd.engine import EngineError
+    engine.lm_forward_logits(pre[:1], from_pos=388)
+    with pytest.raises(EngineError):
+        engine.lm_decode_step(np.zeros(1, dtype=np.int64))
+    gg = np.load(os.path.join(golden_dir, "gen.npz"))
+    toks, _, _, _ = engine.generate(a1, a2, ids, max_len=8, stop_id=-1)
+    assert np.array_equal(toks, gg["tokens"][:, :8])
+    with pytest.raises(EngineError):
+        engine.lm_forward_logits(pre[:1], from_pos=389)
+    with pytest.raises(IndexError):
+        engine.embed_tokens(np.array([49152]))
+    # (e) the reference model object's call surface: model(input_dict).logits, model.generate_prefix_inference(input_dict)
+    d = {"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2), "input": {"input_ids": torch.from_numpy(ids)},
+         "answer": {"input_ids": torch.from_numpy(ans)}}
+    out = engine(d)
+    assert out.loss is None and out.logits.shape == (2, 389 + ans.shape[1], 49152)
+    _close(out.logits[:, f0:, sub], g["logits_sub"], rel=0, atol=3e-3, name="model(input_dict).logits")
+    pfx, _, _ = engine.generate_prefix_inference(d)
+    _close(pfx, e["prefix"], name="generate_prefix_inference(input_dict)")
+
+
 def test_ragged_batch3_matches_reference(engine, golden_dir):
     """B = 3 run by the reference itself (tests/golden/ragged3.npz): tokens exact, third row's prefix and logits in tolerance."""
     g = np.load(os.path.join(golden_dir, "ragged3.npz"))

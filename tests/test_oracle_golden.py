@@ -87,6 +87,22 @@ def test_greedy_tokens_and_logits_match_reference_golden(synth_sd, golden_dir):
     assert np.array_equal(toks2, g["tokens"][:, :2])
 
 
+def test_all_position_logits_match_reference_forward(synth_sd, golden_dir):
+    """the training-time forward (mellow.py:89-98 -> decoder.py:57-90): logits of every position of [prefix | embed(answer)]"""
+    g = np.load(os.path.join(golden_dir, "forward.npz"))
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    ans = torch.from_numpy(g["answer_ids"])
+    with torch.no_grad():
+        emb = O.embed_tokens(synth_sd, ans)
+        logits = O.llama_forward(synth_sd, O.LMParams(), torch.cat((torch.from_numpy(e["prefix"]), emb), 1))
+    assert np.array_equal(emb[:, :, ::9].numpy(), g["answer_embed_sub"])
+    tail = logits[:, int(g["from_pos"]):]
+    assert tail.shape[1] == g["logits_sub"].shape[1]
+    assert np.abs(tail[:, :, g["sub_vocab"]].numpy() - g["logits_sub"]).max() < 2e-3
+    assert np.abs(tail.max(-1).values.numpy() - g["logits_max"]).max() < 2e-3
+    assert np.array_equal(tail.argmax(-1).numpy(), g["argmax"])
+
+
 def test_eos_semantics_match_reference_golden(synth_sd, golden_dir):
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     e = np.load(os.path.join(golden_dir, "enc10.npz"))
