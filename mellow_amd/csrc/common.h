@@ -69,6 +69,59 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
 
+// ---- fp32 = exact sum of three bf16 (gemm_bf16x3.hip) ------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+    h = static_cast<__bf16>(a);                       // round to nearest even (v_cvt_pk_bf16_f32)
+    const float r1 = a - static_cast<float>(h);       // exact
+    m = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(m);      // exact, at most 8 significant bits
+    l = static_cast<__bf16>(r2);                      // exact
+}
+__device__ __forceinline__ void split8(const float (&v)[8], i32x4& p0, i32x4& p1, i32x4& p2) {
+#ifdef MELLOW_X3_FAKESPLIT      // developer A/B build only: wrong numbers, no VALU work (is the split what bounds the loop?)
+    p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+    p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
+    p2 = p0;
+    return;
+#endif
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        split3(v[j], a, b, c);
+        h[j] = a; m[j] = b; l[j] = c;
+    }
+    p0 = __builtin_bit_cast(i32x4, h);
+    p1 = __builtin_bit_cast(i32x4, m);
+    p2 = __builtin_bit_cast(i32x4, l);
+}
+// "APB": an activation matrix [M][K] pre-split for the x3q GEMM, in the order its LDS stage wants it.  16-byte slot index of
+// (row m, columns 8*k8 .. 8*k8+7, piece pc): ((m/128 * K/16 + k8/2) * 12 + pc * 4 + (m/32)%4) * 64 + m%32 + 32 * (k8 % 2)
+__device__ __forceinline__ int64_t apb_slot(int64_t m, int k8, int KT) {
+    return (((m >> 7) * KT + (k8 >> 1)) * 12 + ((m >> 5) & 3)) * 64 + (m & 31) + 32 * (k8 & 1);
+}
+__device__ __forceinline__ void apb_store8(i32x4* apb, int64_t m, int k8, int KT, const float (&w)[8]) {
+    i32x4 p0, p1, p2;
+    split8(w, p0, p1, p2);
+    i32x4* o = apb + apb_slot(m, k8, KT);
+    o[0] = p0; o[4 * 64] = p1; o[8 * 64] = p2;
+}
+// The MFMA epilogues hold a row's columns as quads: lane (h = lane / 32, row = lane % 32) owns columns 8*gq + 4*h + (0..3) of
+// quad group gq.  X = the quad of an even group, Y = of the next (odd) group: one v_permlane32_swap per value gives the lower
+// half-wave all eight columns of the even group and the upper half-wave those of the odd group.
+__device__ __forceinline__ void apb_store_quads(i32x4* apb, int64_t m, int k8_even, int KT, const float (&X)[4], const float (&Y)[4], int h) {
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[j]), __float_as_uint(Y[j]), false, false);
+        w[j] = __uint_as_float(r[0]);
+        w[4 + j] = __uint_as_float(r[1]);
+    }
+    apb_store8(apb, m, k8_even + h, KT, w);
+}
+
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): logical ids that are consecutive land on
 // the same XCD so tiles sharing an operand panel hit one L2.  Bijective for any block count.
 __device__ __forceinline__ int xcd_remap(int b, int nb) {

@@ -143,6 +143,7 @@ struct mellow_engine {
     };
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
+    Buf lm_xn3, lm_o3, lm_h3;                  // f32x3 mode: the GEMM inputs of LM prefill, pre-split by their producers (APB order)
     Buf dec;                                   // one arena for the decode-step buffers (DecArgs)
     Buf dlogits, cand;
     DecArgs da;
@@ -429,7 +430,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     for (void* p : e->allocs) hipFree(p);
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
-                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->kcache, &e->vcache, &e->dec,
+                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->lm_xn3, &e->lm_o3, &e->lm_h3, &e->kcache, &e->vcache, &e->dec,
                                   &e->dlogits, &e->cand, &e->out_tok};
     for (auto* b : bufs)
         if (b->p) hipFree(b->p);
@@ -826,6 +827,19 @@ static int run_gemm(mellow_engine* e, const GemmArgs& a) {
     launch_gemm(a, e->stream);
     return 0;
 }
+// f32x3 mode, LM prefill: the activation arrives pre-split in APB order from its producer (a3) and both operands are staged
+// by LDS-DMA (gemm_x3q_kernel); counted in the same profile family as every other dense GEMM
+static int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3) {
+    auto it = e->bf_w.find(a.Wp);
+    if (it == e->bf_w.end()) return fail("internal: no bf16-split copy of this weight");
+    GemmArgs g = a;
+    g.A8 = reinterpret_cast<const uint8_t*>(a3);
+    g.W8 = reinterpret_cast<const uint8_t*>(it->second);
+    ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+    ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 300;
+    launch_gemm_bf16x3_apb(g, e->stream);
+    return 0;
+}
 static GemmArgs lin(const float* A, int64_t lda, int M, const Packed& w, float* C, int64_t ldc, const float* bias) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.M = M; g.K = w.KP; g.Wp = w.p; g.Nw = w.Nw; g.N = rup(w.N, 4); g.C = C; g.ldc = ldc; g.bias = bias;
@@ -996,6 +1010,12 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
     CHK(ensure(e, e->lm_q, Mp * 576));
     CHK(ensure(e, e->lm_o, Mp * 576));
     CHK(ensure(e, e->lm_h, Mp * 1536));
+    if (e->f32x3_terms) {                       // 6 bytes per element, rows padded to whole 128-row panels
+        const size_t Mq = (size_t)rup((int)Mp, 128);
+        CHK(ensure(e, e->lm_xn3, Mq * 576 * 6 / 4));
+        CHK(ensure(e, e->lm_o3, Mq * 576 * 6 / 4));
+        CHK(ensure(e, e->lm_h3, Mq * 1536 * 6 / 4));
+    }
     const int Bp = rb_of(B) * 32;
     if (e->kv_B != Bp || e->kv_Tmax != Tmax) {
         e->kv_B = Bp;
@@ -1104,17 +1124,22 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bo
     const int M = B * T, Tmax = e->kv_Tmax;
     const int NL = e->cfg.num_layers;
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
+    static const bool no_apb = getenv("MELLOW_X3_NO_APB") != nullptr;        // developer A/B: the register-staged x3p kernel
+    const bool apb = e->f32x3_terms && !no_apb;
     for (int l = 0; l < NL; ++l) {
         const LMLayerW& w = e->layers[l];
         float* kc = e->kcache.p + kv_layer_floats(e) * l;
         float* vc = e->vcache.p + kv_layer_floats(e) * l;
-        { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
+        // f32x3 mode: every GEMM input of the layer is written by its producer already split into three bf16 pieces, in the
+        // order the GEMM's LDS stage wants it (APB, common.h), and the GEMM stages both operands by LDS-DMA (x3q)
+        if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * M * 576 * 4); launch_rmsnorm_apb(x, e->lm_xn3.p, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
+        else { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
         {
             GemmArgs g;
             g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.qkv.p; g.Nw = 960; g.N = 960; g.epi = EPI_QKV_ROPE;
             g.q_out = e->lm_q.p; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
             g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
-            CHK(run_gemm(e, g));
+            if (apb) CHK(run_gemm_apb(e, g, e->lm_xn3.p)); else CHK(run_gemm(e, g));
         }
         // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
         // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
@@ -1122,24 +1147,25 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bo
         {
             // causal QK^T + PV: 4*64 flops per (query,key) pair per head
             ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
-            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, B, T, Tmax, s);
+            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, apb ? e->lm_o3.p : nullptr, B, T, Tmax, s);
         }
         {
             GemmArgs g = lin(e->lm_o.p, 576, M, w.o, x, 576, nullptr);
             g.resid = x; g.ldr = 576;
-            CHK(run_gemm(e, g));
+            if (apb) CHK(run_gemm_apb(e, g, e->lm_o3.p)); else CHK(run_gemm(e, g));
         }
-        { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
+        if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * M * 576 * 4); launch_rmsnorm_apb(x, e->lm_xn3.p, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
+        else { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
         {
             GemmArgs g;
             g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.gateup.p; g.Nw = 3072; g.N = 1536; g.C = e->lm_h.p; g.ldc = 1536;
             g.epi = EPI_SWIGLU;
-            CHK(run_gemm(e, g));
+            if (apb) { g.C3 = e->lm_h3.p; CHK(run_gemm_apb(e, g, e->lm_xn3.p)); } else CHK(run_gemm(e, g));
         }
         {
             GemmArgs g = lin(e->lm_h.p, 1536, M, w.down, x, 576, nullptr);
             g.resid = x; g.ldr = 576;
-            CHK(run_gemm(e, g));
+            if (apb) CHK(run_gemm_apb(e, g, e->lm_h3.p)); else CHK(run_gemm(e, g));
         }
     }
     if (all_positions) {        // x = the hidden states after all layers, every position (mellow_lm_forward_logits)
@@ -1632,7 +1658,7 @@ int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, flo
 int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C_out,
                           int iters, float* ms2) {
     if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return fail("bad argument");
-    if (mode != 0 && mode != 6 && mode != 9 && mode != 16) return fail("mode must be 0, 6, 9 or 16 (fused 6-term)");
+    if (mode != 0 && mode != 6 && mode != 9 && mode != 16 && mode != 17) return fail("mode must be 0, 6, 9, 16 (fused 6-term) or 17 (pre-split A, LDS-DMA)");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int NP = rup(N, 128);
@@ -1642,7 +1668,7 @@ int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, i
     HIPCHK(hipMalloc(&dW, (size_t)N * K * 4));
     HIPCHK(hipMalloc(&dWp, (size_t)NP * K * 4));
     HIPCHK(hipMalloc(&dC, (size_t)M * N * 4));
-    HIPCHK(hipMalloc(&dA3, (size_t)M * K * 6));
+    HIPCHK(hipMalloc(&dA3, (size_t)rup(M, 128) * K * 6));
     HIPCHK(hipMalloc(&dPB, (size_t)NP * K * 6));
     HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dW, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
@@ -1654,6 +1680,7 @@ int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, i
     auto run = [&](bool pre, bool main) {
         if (mode == 0) { if (main) launch_gemm(g, s); }
         else if (mode == 16) { if (main) launch_gemm_bf16x3_fused(g, s); }
+        else if (mode == 17) { if (pre) launch_split_rows_apb(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3_apb(g, s); }
         else { if (pre) launch_split_rows(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3(g, mode, s); }
     };
     run(true, true);

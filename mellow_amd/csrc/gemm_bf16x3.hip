@@ -19,35 +19,6 @@
 
 namespace mellow {
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
-    h = static_cast<__bf16>(a);                       // round to nearest even (v_cvt_pk_bf16_f32)
-    const float r1 = a - static_cast<float>(h);       // exact
-    m = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(m);      // exact, at most 8 significant bits
-    l = static_cast<__bf16>(r2);                      // exact
-}
-__device__ __forceinline__ void split8(const float (&v)[8], i32x4& p0, i32x4& p1, i32x4& p2) {
-#ifdef MELLOW_X3_FAKESPLIT      // developer A/B build only: wrong numbers, no VALU work (is the split what bounds the loop?)
-    p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-    p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
-    p2 = p0;
-    return;
-#endif
-    bf16x8 h, m, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 a, b, c;
-        split3(v[j], a, b, c);
-        h[j] = a; m[j] = b; l[j] = c;
-    }
-    p0 = __builtin_bit_cast(i32x4, h);
-    p1 = __builtin_bit_cast(i32x4, m);
-    p2 = __builtin_bit_cast(i32x4, l);
-}
-
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ A, int64_t lda, int M, int K,
                                                          i32x4* __restrict__ A3, int64_t ld3 /* i32x4 per row = 3 K/8 */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -422,16 +393,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     // iteration t: fragments of tile t+1 (complete since the last barrier) -> registers; MFMAs of tile t; registers (tile t+2,
     // loaded one whole iteration ago) split -> stage (t+2) % 3, whose last readers finished in iteration t-2; loads of tile
     // t+4 -> the same registers (two sets alternate); barrier.  Unrolled by 6: stage indices and register sets are static.
+    // MELLOW_X3_ABL (developer ablation, wrong results): bit 0 no global loads, 1 no barrier, 2 no LDS stores, 3 no fragment
+    // reads in the loop -- what each part costs on top of the 24 MFMAs (tools/README.md)
+#ifndef MELLOW_X3_ABL
+#define MELLOW_X3_ABL 0
+#endif
 #define X3_ITER(T, SN, SW, FA, FW, FAN, FWN, ra, rw)                                             \
     if ((T) < KT) {                                                                              \
         X3_PRIO(2)                                                                               \
-        X3_FRAGS(SN, FAN, FWN)                                                                   \
+        if (!(MELLOW_X3_ABL & 8)) X3_FRAGS(SN, FAN, FWN)                                         \
         X3_MFMAS(FA, FW)                                                                         \
-        X3_LSTORE(SW, ra, rw)                                                                    \
-        X3_GLOAD((T) + 4, ra, rw)                                                                \
-        X3_SCHED()                                                                               \
+        if (!(MELLOW_X3_ABL & 4)) X3_LSTORE(SW, ra, rw)                                          \
+        if (!(MELLOW_X3_ABL & 1)) X3_GLOAD((T) + 4, ra, rw)                                      \
+        if (!MELLOW_X3_ABL) X3_SCHED()                                                           \
         X3_PRIO(0)                                                                               \
-        __syncthreads();                                                                         \
+        if (!(MELLOW_X3_ABL & 2)) __syncthreads();                                               \
     }
     for (int kt = 0; kt < KT; kt += 6) {
         X3_ITER(kt + 0, 1, 2, fa0, fw0, fa1, fw1, raA, rwA)
@@ -452,7 +428,200 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
 
+// ---- "x3q": both operands arrive pre-split in fragment order and go global -> LDS by LDS-DMA ------------------------------
+// The ablations of the kernel above (MELLOW_X3_ABL, K = 4608: all parts 184 TF-eq; without the LDS stores + split 249; without
+// the global loads 228; MFMAs alone 320) say the register staging is what the loop pays for.  Here A is split by its PRODUCER
+// into the same [piece][32-row tile][lane] 16-byte order the weight already has ("APB": per 128-row panel and k16 tile 12 KiB
+// contiguous), so a stage of either operand is twelve 1-KiB `global_load_lds_dwordx4` (wave-uniform LDS base + lane * 16): no
+// staging registers, no VALU, no ds_write.  Three stages: during iteration t the fragments of tile t+1 are read, tile t+2 is
+// landing and tile t+3 is issued into the stage tile t occupied (its fragments have been in registers since iteration t-1).
+// The LDS-DMA loads are issued from inline asm, which hipcc does not count: the waits are explicit (vmcnt(6): the six loads of
+// tile t+3 may stay in flight across the barrier).
+__device__ __forceinline__ void glds16(const void* base, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(base) : "memory");
+}
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
+    constexpr int BM = 128, BN = 128, WN = 2, NST = 3;
+    constexpr int STAGE = 3 * 4 * 64;                                       // i32x4 per operand per stage
+    extern __shared__ __attribute__((aligned(16))) i32x4 smem_bf[];
+    i32x4* As = smem_bf;
+    i32x4* Ws = smem_bf + NST * STAGE;
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
+    const int pm = L / p.gn, pn = L % p.gn;
+    const int KT = g.K >> 4;
+    // waves 0,1 carry the A stage (chunks wave*6 .. +5 of 12), waves 2,3 the W stage
+    const bool isA = wave < 2;
+    const int c0 = (wave & 1) * 6;
+    const char* base = isA ? reinterpret_cast<const char*>(g.A8) + ((int64_t)pm * KT * 12 + c0) * 1024
+                           : reinterpret_cast<const char*>(g.W8) + (int64_t)pn * 4 * KT * 3072;
+    const uint32_t kstep = isA ? 12288u : 3072u;
+    uint32_t voff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = c0 + j;                                               // W chunk c = piece * 4 + n-tile
+        voff[j] = isA ? (uint32_t)(j * 1024 + lane * 16) : (uint32_t)(((c & 3) * KT * 192 + (c >> 2) * 64 + lane) * 16);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_bf + (isA ? 0u : (uint32_t)(NST * STAGE * 16)) + (uint32_t)c0 * 1024u;
+#define X3Q_ISSUE(T, ST)                                                                         \
+    {                                                                                            \
+        const int t_ = (T) < KT ? (T) : KT - 1;                                                  \
+        const char* b_ = base + (int64_t)t_ * kstep;                                             \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) glds16(b_, voff[j], lds0 + (uint32_t)((ST) * STAGE * 16 + j * 1024)); \
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define X3Q_FRAGS(ST, FA, FW)                                                                    \
+    {                                                                                            \
+        const i32x4* Ac = As + (ST) * STAGE + (2 * wm) * 64 + lane;                              \
+        const i32x4* Wc = Ws + (ST) * STAGE + (2 * wn) * 64 + lane;                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                            \
+            _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                   \
+                FA[t][pc] = Ac[(pc * 4 + t) * 64];                                               \
+                FW[t][pc] = Wc[(pc * 4 + t) * 64];                                               \
+            }                                                                                    \
+    }
+#define X3Q_TERM(FA, FW, PW, PA)                        \
+    MELLOW_BF(FW[0][PW], FA[0][PA], acc[0][0])          \
+    MELLOW_BF(FW[0][PW], FA[1][PA], acc[0][1])          \
+    MELLOW_BF(FW[1][PW], FA[0][PA], acc[1][0])          \
+    MELLOW_BF(FW[1][PW], FA[1][PA], acc[1][1])
+#define X3Q_MFMAS(FA, FW) X3Q_TERM(FA, FW, 2, 0) X3Q_TERM(FA, FW, 0, 2) X3Q_TERM(FA, FW, 1, 1) X3Q_TERM(FA, FW, 1, 0) X3Q_TERM(FA, FW, 0, 1) X3Q_TERM(FA, FW, 0, 0)
+#define X3Q_SCHED()                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        if (i_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+    }
+    i32x4 fa0[2][3], fw0[2][3], fa1[2][3], fw1[2][3];
+    X3Q_ISSUE(0, 0)
+    X3Q_ISSUE(1, 1)
+    X3Q_ISSUE(2, 2)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        // tiles 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();
+    X3Q_FRAGS(0, fa0, fw0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // stage 0 is free for tile 3
+#ifndef MELLOW_X3Q_VAR
+#define MELLOW_X3Q_VAR 8
+#endif
+    // developer variants (tools/ab_build.sh -DMELLOW_X3Q_VAR=bits): 1 no LDS-DMA in the loop (wrong), 2 no vmcnt wait (wrong),
+    // 4 no setprio, 8 LDS-DMA issued between the last 12 MFMAs instead of before the first
+#define X3Q_WAIT() if (MELLOW_X3Q_VAR & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+#define X3Q_ITER(T, S0, S1, FA, FW, FAN, FWN)                                                    \
+    if ((T) < KT) {                                                                              \
+        if (!(MELLOW_X3Q_VAR & 9)) X3Q_ISSUE((T) + 3, S0)                                        \
+        if (!(MELLOW_X3Q_VAR & 4)) __builtin_amdgcn_s_setprio(2);                                \
+        X3Q_FRAGS(S1, FAN, FWN)                                                                  \
+        if (MELLOW_X3Q_VAR & 8) {                                                                \
+            X3Q_TERM(FA, FW, 2, 0) X3Q_TERM(FA, FW, 0, 2) X3Q_TERM(FA, FW, 1, 1)                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                  \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            const int t_ = (T) + 3 < KT ? (T) + 3 : KT - 1;                                      \
+            const char* b_ = base + (int64_t)t_ * kstep;                                         \
+            _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                      \
+                glds16(b_, voff[j], lds0 + (uint32_t)((S0) * STAGE * 16 + j * 1024));            \
+                if (j == 0) { MELLOW_BF(FW[0][1], FA[0][0], acc[0][0]) MELLOW_BF(FW[0][1], FA[1][0], acc[0][1]) } \
+                if (j == 1) { MELLOW_BF(FW[1][1], FA[0][0], acc[1][0]) MELLOW_BF(FW[1][1], FA[1][0], acc[1][1]) } \
+                if (j == 2) { MELLOW_BF(FW[0][0], FA[0][1], acc[0][0]) MELLOW_BF(FW[0][0], FA[1][1], acc[0][1]) } \
+                if (j == 3) { MELLOW_BF(FW[1][0], FA[0][1], acc[1][0]) MELLOW_BF(FW[1][0], FA[1][1], acc[1][1]) } \
+                if (j == 4) { MELLOW_BF(FW[0][0], FA[0][0], acc[0][0]) MELLOW_BF(FW[0][0], FA[1][0], acc[0][1]) } \
+                if (j == 5) { MELLOW_BF(FW[1][0], FA[0][0], acc[1][0]) MELLOW_BF(FW[1][0], FA[1][0], acc[1][1]) } \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+            }                                                                                    \
+        } else {                                                                                 \
+            X3Q_MFMAS(FA, FW)                                                                    \
+            X3Q_SCHED()                                                                          \
+        }                                                                                        \
+        if (!(MELLOW_X3Q_VAR & 4)) __builtin_amdgcn_s_setprio(0);                                \
+        X3Q_WAIT()                                                                               \
+        __builtin_amdgcn_s_barrier();                                                            \
+    }
+    for (int kt = 0; kt < KT; kt += 6) {
+        X3Q_ITER(kt + 0, 0, 1, fa0, fw0, fa1, fw1)
+        X3Q_ITER(kt + 1, 1, 2, fa1, fw1, fa0, fw0)
+        X3Q_ITER(kt + 2, 2, 0, fa0, fw0, fa1, fw1)
+        X3Q_ITER(kt + 3, 0, 1, fa1, fw1, fa0, fw0)
+        X3Q_ITER(kt + 4, 1, 2, fa0, fw0, fa1, fw1)
+        X3Q_ITER(kt + 5, 2, 0, fa1, fw1, fa0, fw0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the clamped re-loads of the last tiles
+#undef X3Q_ISSUE
+#undef X3Q_FRAGS
+#undef X3Q_TERM
+#undef X3Q_MFMAS
+#undef X3Q_SCHED
+#undef X3Q_ITER
+#undef X3Q_WAIT
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
+}
+
 #undef MELLOW_BF
+
+// A fp32 [M][lda] -> APB: i32x4 index ((panel * K/16 + kt) * 12 + piece * 4 + tile) * 64 + lane, row = panel * 128 + tile * 32
+// + lane % 32, k = kt * 16 + (lane / 32) * 8 .. + 7; rows >= M are written as zeros (the buffer holds roundup(M, 128) rows)
+__global__ __launch_bounds__(256) void split_rows_apb_kernel(const float* __restrict__ A, int64_t lda, int M, int K, i32x4* __restrict__ out) {
+    const int KT = K >> 4;
+    const int64_t total = (int64_t)((M + 127) / 128) * KT * 256;            // one thread per (panel, kt, tile, lane)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), tile = (int)((i >> 6) & 3);
+        const int64_t pk = i >> 8;
+        const int kt = (int)(pk % KT);
+        const int64_t panel = pk / KT;
+        const int64_t m = panel * 128 + tile * 32 + (lane & 31);
+        const int k = kt * 16 + (lane >> 5) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < M) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(A + m * lda + k), y = *reinterpret_cast<const f32x4*>(A + m * lda + k + 4);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        }
+        i32x4 p0, p1, p2;
+        split8(v, p0, p1, p2);
+        i32x4* o = out + (pk * 12 + tile) * 64 + lane;
+        o[0] = p0; o[4 * 64] = p1; o[8 * 64] = p2;
+    }
+}
+void launch_split_rows_apb(const float* A, int64_t lda, int M, int K, void* out, hipStream_t s) {
+    const int64_t total = (int64_t)((M + 127) / 128) * (K >> 4) * 256;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_rows_apb_kernel, dim3(blocks), dim3(256), 0, s, A, lda, M, K, reinterpret_cast<i32x4*>(out));
+}
+template <int EPI>
+static void launchq(const GemmArgs& a, hipStream_t s) {
+    GemmBDev d;
+    d.a = a;
+    d.gm = (a.M + 127) / 128;
+    d.gn = (a.Nw + 127) / 128;
+    const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                              // 72 KiB
+    static bool attr_q = false;
+    if (!attr_q) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_q = true;
+    }
+    hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+}
+// g.A8 = APB (launch_split_rows_apb or a producer's split output), g.W8 = PB; K % 16 == 0, K >= 48
+void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_LINEAR: launchq<EPI_LINEAR>(a, s); break;
+        case EPI_SWIGLU: launchq<EPI_SWIGLU>(a, s); break;
+        case EPI_QKV_ROPE: launchq<EPI_QKV_ROPE>(a, s); break;
+        default: break;
+    }
+}
 
 template <int EPI>
 static void launchb(const GemmArgs& a, int terms, hipStream_t s) {

@@ -50,6 +50,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         } else {
             // pair epilogues: n-tile 2*wn holds the first half of the pair, 2*wn+1 the second
             const int P = pn * WN + wn;  // 64-column group index
+            if constexpr (EPI == EPI_SWIGLU) {
+                if (g.C3) {       // the consumer is an x3q GEMM: write silu(gate) * up pre-split in APB order (N % 16 == 0)
+                    if (P * 32 >= g.N) continue;
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        float X[4], Y[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            X[j] = __fmul_rn(siluf_(acc[0][mi][8 * gp + j]), acc[1][mi][8 * gp + j]);
+                            Y[j] = __fmul_rn(siluf_(acc[0][mi][8 * gp + 4 + j]), acc[1][mi][8 * gp + 4 + j]);
+                        }
+                        apb_store_quads(reinterpret_cast<i32x4*>(g.C3), m, P * 4 + 2 * gp, g.N >> 4, X, Y, h);
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int i0 = 8 * gq + 4 * h;  // 0..31 within the pair

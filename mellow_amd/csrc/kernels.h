@@ -58,6 +58,8 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
+    // EPI_SWIGLU only: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C
+    void* C3 = nullptr;
     // fp8 mode (gemm_fp8.hip): both operands e4m3, fp32 accumulate, C = (A8 . W8^T) * a_scale[m] * w_scale[n] (+epilogue)
     const uint8_t* A8 = nullptr;      // row-major [M][lda8] bytes, lda8 = K rounded up to 64
     int64_t lda8 = 0;
@@ -78,7 +80,10 @@ void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, 
 void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s);
 void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s);
 void launch_gemm_bf16x3(const GemmArgs& a, int terms /* 6 or 9 partial products */, hipStream_t s);   // K % 16 == 0
-void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s);   // A split in registers (no pre-pass), K % 32 == 0, a_mode == A_PLAIN
+void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s);
+// pre-split A in fragment order ("APB", A8) + PB weight (W8), both staged by LDS-DMA
+void launch_split_rows_apb(const float* A, int64_t lda, int M, int K, void* out, hipStream_t s);
+void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s);   // A split in registers (no pre-pass), K % 32 == 0, a_mode == A_PLAIN
 double gemm_flops(const GemmArgs& a);
 
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------
@@ -175,6 +180,8 @@ void launch_layernorm(const float* in, float* out, int M, int C, const float* w,
 void launch_merge_layernorm(const float* in, float* out, int n, int R, int C, const float* w, const float* b,
                             hipStream_t s);
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s);
+// the same numbers, written pre-split in APB order (C % 16 == 0) for the x3q GEMM
+void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s);
 
 // ---- Swin window attention -----------------------------------------------------------------------------
 // qkv [M][3C] rows in window order; out [M][C] window order.  bias_exp [nH][64][64]; mask [nW][64][64] or null
@@ -204,7 +211,8 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 
 // ---- LM attention --------------------------------------------------------------------------------------
 // causal GQA flash attention over the KV pages written by the QKV epilogue.  q [B*T][576]; o [B*T][576]
-void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
+// o_apb != nullptr: the output [B*T][576] is written pre-split in APB order instead of to o
+void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
                               int Tmax, hipStream_t s);
 // ---- misc ------------------------------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);

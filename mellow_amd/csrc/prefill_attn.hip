@@ -23,7 +23,7 @@ __device__ __forceinline__ float pa_exp(float x) { return __builtin_amdgcn_exp2f
 __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __restrict__ q,
                                                                 const float* __restrict__ k_cache,
                                                                 const float* __restrict__ v_cache,
-                                                                float* __restrict__ o, int T, int Tmax) {
+                                                                float* __restrict__ o, i32x4* __restrict__ o_apb, int T, int Tmax) {
     // wave specialisation: waves 0..2 = the three query heads of kv head g (MFMA + softmax), wave 3 = loader: it owns
     // the global -> LDS staging (K transposed, V row-major) of the NEXT key tile into the other LDS stage while the
     // compute waves work, so they carry no staging registers (148 VGPRs -> three workgroups per CU) and never wait
@@ -141,22 +141,36 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
     }
     if (qi < T) {
         const float inv = 1.0f / l_run;
-        float* orow = o + ((int64_t)b * T + qi) * 576 + hq * 64;
+        if (o_apb) {      // the o_proj is an x3q GEMM: write the row pre-split in APB order (K = 576: 72 column octets)
+            const int64_t m = (int64_t)b * T + qi;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int d = 8 * gq + 4 * h;
-            *reinterpret_cast<float4*>(orow + d) =
-                make_float4(O0[4 * gq] * inv, O0[4 * gq + 1] * inv, O0[4 * gq + 2] * inv, O0[4 * gq + 3] * inv);
-            *reinterpret_cast<float4*>(orow + 32 + d) =
-                make_float4(O1[4 * gq] * inv, O1[4 * gq + 1] * inv, O1[4 * gq + 2] * inv, O1[4 * gq + 3] * inv);
+            for (int gp = 0; gp < 2; ++gp) {
+                float X[4], Y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { X[j] = O0[8 * gp + j] * inv; Y[j] = O0[8 * gp + 4 + j] * inv; }
+                apb_store_quads(o_apb, m, hq * 8 + 2 * gp, 36, X, Y, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { X[j] = O1[8 * gp + j] * inv; Y[j] = O1[8 * gp + 4 + j] * inv; }
+                apb_store_quads(o_apb, m, hq * 8 + 4 + 2 * gp, 36, X, Y, h);
+            }
+        } else {
+            float* orow = o + ((int64_t)b * T + qi) * 576 + hq * 64;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d = 8 * gq + 4 * h;
+                *reinterpret_cast<float4*>(orow + d) =
+                    make_float4(O0[4 * gq] * inv, O0[4 * gq + 1] * inv, O0[4 * gq + 2] * inv, O0[4 * gq + 3] * inv);
+                *reinterpret_cast<float4*>(orow + 32 + d) =
+                    make_float4(O1[4 * gq] * inv, O1[4 * gq + 1] * inv, O1[4 * gq + 2] * inv, O1[4 * gq + 3] * inv);
+            }
         }
     }
 }
 
-void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, int B, int T,
+void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
                               int Tmax, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, T, Tmax);
+    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
 }
 
 }  // namespace mellow
