@@ -249,20 +249,26 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2, KT = C >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
+    // all eight rows of the wave are loaded before the first reduction (rows past M: a clamped re-read, result unused)
+    float ss[8];
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int64_t m = m0 + wave * 8 + i;
-        if (m >= M) break;
+        int64_t m = m0 + wave * 8 + i;
+        m = m < M ? m : M - 1;
         const float4* src = reinterpret_cast<const float4*>(in + m * C);
-        float ss = 0.f;
+        ss[i] = 0.f;
 #pragma unroll
         for (int q = 0; q < LN_MAXV; ++q) {
             const int v = lane + 64 * q;
             if (v < nv) {
                 const float4 x = src[v];
-                ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+                ss[i] += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
             }
         }
-        const float r = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float r = 1.0f / sqrtf(wave_sum(ss[i]) / (float)C + eps);
         if (lane == 0) rs[wave * 8 + i] = r;
     }
     __syncthreads();
