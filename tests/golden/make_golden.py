@@ -198,6 +198,28 @@ def late_case(args, model, prefix, t0):
     )
 
 
+B32_STEPS = 8
+
+
+def b32_case(args, model, t0):
+    """BASELINE configs[1]'s batch (the bench.py workload: examples 0..31) through the reference itself: 8 greedy steps of
+    all 32 rows, a sub-sample of every row's prefix, and every row's last-position logits (sub-vocabulary) of all steps."""
+    a1, a2, ids = synth.make_batch(32)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
+                                                        "input": {"input_ids": torch.from_numpy(ids)}})
+        print(f"b32 prefix ({time.time() - t0:.1f}s)")
+        _, toks, logits_log = ref_generate_tokens(model, prefix, B32_STEPS, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    L = torch.stack(logits_log)                                             # (steps,32,V)
+    top2 = torch.topk(L, 2, dim=-1).values
+    gaps = (top2[..., 0] - top2[..., 1]).numpy()
+    print(f"b32 tokens ({time.time() - t0:.1f}s): min top-2 gap {gaps.min():.4f}\n{toks}")
+    np.savez_compressed(os.path.join(args.out, "b32.npz"), steps=B32_STEPS, tokens=toks, top2_gap=gaps,
+                        prefix_sub=prefix[:, ::7, ::5].numpy(), logits_sub=L[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB,
+                        logits_max=L.max(-1).values.numpy())
+
+
 FWD_ANSWER_LEN = 12
 FWD_FROM = 380
 
@@ -273,7 +295,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32 "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -368,6 +390,8 @@ def main():
         late_case(args, model, prefix, t0)
     if want("forward"):
         forward_case(args, model, a1t, a2t, idst, prefix, t0)
+    if "b32" in only or (not only and not args.skip_long):
+        b32_case(args, model, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
     print(f"done ({time.time() - t0:.1f}s)")

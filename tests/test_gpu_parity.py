@@ -350,6 +350,29 @@ def test_all_position_forward_matches_reference(engine, batch2, golden_dir):
     _close(pfx, e["prefix"], name="generate_prefix_inference(input_dict)")
 
 
+def test_batch32_matches_reference(engine, golden_dir):
+    """BASELINE configs[1]'s batch -- the 32 examples `bench.py` times -- against the REFERENCE run on the same 32 examples
+    (tests/golden/b32.npz: unmodified `generate_prefix_inference` + `_generate_batch`, 8 steps; minimum top-2 gap 0.043):
+    every row's greedy tokens are equal, every row's prefix agrees, and the last-position logits of all 8 steps (teacher-forced
+    with the reference's tokens, so a late divergence cannot hide an early one) agree within the 3e-3 of the fp32 path."""
+    g = np.load(os.path.join(golden_dir, "b32.npz"))
+    a1, a2, ids = synth.make_batch(32)
+    steps = int(g["steps"])
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=steps, stop_id=-1)
+    bad = np.argwhere(toks != g["tokens"])
+    assert n == steps and bad.size == 0, f"first divergence from the reference at (row, step) {bad[0].tolist()}"
+    pre = engine.prefix(a1, a2, ids)
+    _close(pre[:, ::7, ::5], g["prefix_sub"], name="prefix of all 32 rows (sub-sampled)")
+    sub = torch.from_numpy(g["sub_vocab"])
+    logits = engine.lm_prefill(pre, reserve=steps)
+    for i in range(steps):
+        if i:
+            logits = engine.lm_decode_step(g["tokens"][:, i - 1])
+        _close(logits[:, sub], g["logits_sub"][i], rel=0, atol=3e-3, name=f"logits of 32 rows at step {i}")
+        _close(logits.max(-1).values, g["logits_max"][i], rel=0, atol=3e-3, name=f"max logit at step {i}")
+        assert logits.argmax(-1).cpu().tolist() == g["tokens"][:, i].tolist()
+
+
 def test_ragged_batch3_matches_reference(engine, golden_dir):
     """B = 3 run by the reference itself (tests/golden/ragged3.npz): tokens exact, third row's prefix and logits in tolerance."""
     g = np.load(os.path.join(golden_dir, "ragged3.npz"))

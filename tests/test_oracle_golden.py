@@ -103,6 +103,18 @@ def test_all_position_logits_match_reference_forward(synth_sd, golden_dir):
     assert np.array_equal(tail.argmax(-1).numpy(), g["argmax"])
 
 
+def test_batch32_rows_match_reference_golden(synth_sd, golden_dir):
+    """three rows of the 32-example reference run (tests/golden/b32.npz): the oracle's prefix and first two tokens"""
+    g = np.load(os.path.join(golden_dir, "b32.npz"))
+    rows = [5, 17, 31]
+    a1, a2, ids = synth.make_examples(rows)
+    with torch.no_grad():
+        prefix = O.generate_prefix_inference(synth_sd, torch.from_numpy(a1), torch.from_numpy(a2), torch.from_numpy(ids))
+        toks = O.generate_batch(synth_sd, O.LMParams(), prefix, 2, 0.8, 1.0, -1).numpy()
+    _close(prefix[:, ::7, ::5].numpy(), g["prefix_sub"][rows], rtol=1e-4)
+    assert np.array_equal(toks, g["tokens"][rows, :2])
+
+
 def test_eos_semantics_match_reference_golden(synth_sd, golden_dir):
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     e = np.load(os.path.join(golden_dir, "enc10.npz"))
