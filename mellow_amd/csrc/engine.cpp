@@ -1193,10 +1193,13 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
 static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, bool inc_pos) {
     hipStream_t s = e->stream;
     const int Bp = e->da.rows;
+    // developer knobs (wrong tokens, timing only): every layer on layer 0's weights / KV pages -- is a decode kernel's time the
+    // cold fetch of its weights (538 MB per step cycle through the 256 MB Infinity Cache) or of its KV pages?
+    static const bool same_w = getenv("MELLOW_DEV_SAME_WEIGHTS") != nullptr, same_kv = getenv("MELLOW_DEV_SAME_KV") != nullptr;
     for (int l = l_begin; l < l_end; ++l) {
-        const LMLayerW& w = e->layers[l];
-        float* kc = e->kcache.p + kv_layer_floats(e) * l;
-        float* vc = e->vcache.p + kv_layer_floats(e) * l;
+        const LMLayerW& w = e->layers[same_w ? 0 : l];
+        float* kc = e->kcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
+        float* vc = e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         DecArgs a = e->da;
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
