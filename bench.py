@@ -356,7 +356,10 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
                 pj = json.load(f)
-            if pj.get("source_sha16") == kernel_source_sha16():
+            if pj.get("precision", "f32x3") != args.precision:
+                traffic_note = (f"profiles/{PMC_TRAFFIC_FILE} was measured in the {pj.get('precision', 'f32x3')} mode, this run is "
+                                f"{args.precision}: not printed")
+            elif pj.get("source_sha16") == kernel_source_sha16():
                 traffic = round(pj["traffic_bytes_per_launch"])
                 traffic_note = f"bytes per launch (memory-side, PMC, profiles/{PMC_TRAFFIC_FILE}, same kernel sources)"
             else:
@@ -401,7 +404,7 @@ def main():
                                     "STFT / mel stay on gemm_f32_kernel; peak = 2.5 PF dense bf16 / 6" if args.precision == "f32x3"
                                     else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),
                          "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(tf / peak, 4), "traffic": None if args.precision != "f32" else traffic,
+                         "frac": round(tf / peak, 4), "traffic": traffic,
                          "traffic_unit": traffic_note,
                          "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
                          "flops_per_step": flops_alg,

@@ -30,8 +30,9 @@ assert nf == nw and nf > 0, (nf, nw)
 out = {
     "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill) / gemm_x3p_kernel / gemm_bf16x3f_kernel (f32x3 mode) + gemm_f32_kernel (all instances)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py "
-              "(2 encoder+prefill passes at B=32, precision f32x3); reduced with tools/pmc_traffic.py",
+              "(2 encoder+prefill passes at B=32, in the `precision` mode below); reduced with tools/pmc_traffic.py",
     "source_sha16": kernel_source_sha16(),
+    "precision": os.environ.get("MELLOW_PRECISION", "f32x3"),      # the mode tools/pmc_prefill.py ran in
     "launches": nf,
     "fetch_size_kb_per_launch": fetch / nf,
     "write_size_kb_per_launch": write / nw,
