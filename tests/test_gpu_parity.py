@@ -685,7 +685,7 @@ def test_f32x3_mode_is_fp32_accurate(engine_f32, synth_sd, golden_dir):
     W = torch.randn(576, 576) * 0.05
     exact = A.double() @ W.double().T
     e_mfma = (engine_f32.debug_gemm_f32(A, W, mode=0)[0].double() - exact).abs()
-    for mode in (6, 9, 16):
+    for mode in (6, 9, 16, 17):
         e_x3 = (engine_f32.debug_gemm_f32(A, W, mode=mode)[0].double() - exact).abs()
         assert float(e_x3.max()) <= 1.25 * float(e_mfma.max()) and float(e_x3.pow(2).mean()) <= 1.25 ** 2 * float(e_mfma.pow(2).mean())
     e3 = Engine(device=0, precision="f32x3")
@@ -700,6 +700,24 @@ def test_f32x3_mode_is_fp32_accurate(engine_f32, synth_sd, golden_dir):
     prefix = torch.from_numpy(e["prefix"])
     _close(e3.lm_prefill(prefix, reserve=2), engine_f32.lm_prefill(prefix, reserve=2), rel=0, atol=3e-3, name="f32x3 prefill logits")
     e3.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(389, 576, 576), (12448, 960, 576), (1000, 3072, 576), (517, 576, 1536), (129, 128, 192),
+                                   (128, 4, 224), (1, 640, 4608), (4097, 292, 256)])
+def test_lds_dma_gemm_is_bit_identical_to_register_staged(engine_f32, M, N, K):
+    """`gemm_x3q_kernel` (pre-split activation in fragment order, both operands staged by LDS-DMA with hand-counted waits; mode
+    17 of the debug tap) multiplies the same bf16 pieces in the same order as `gemm_x3p_kernel` (mode 16): the results must be
+    equal BIT FOR BIT on ragged M (padding rows of the last 128-row panel are never written by the split kernel), N that is not
+    a multiple of the 128-column tile, K of 12 .. 288 k16-tiles, and on repetition (a missed wait would show as a flaky row)."""
+    torch.manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K) * (0.2 + 3 * torch.rand(M, 1))
+    W = torch.randn(N, K) * 0.05 * (1 + torch.rand(N, 1))
+    want = engine_f32.debug_gemm_f32(A, W, mode=16)[0]
+    for _ in range(3):
+        got = engine_f32.debug_gemm_f32(A, W, mode=17)[0]
+        assert torch.equal(got, want)
+    exact = A.double() @ W.double().T
+    assert float((want.double() - exact).abs().max()) <= 2e-6 * float(exact.abs().max()) + 1e-30
 
 
 def test_degenerate_audio_matches_oracle(engine, synth_sd):
