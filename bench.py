@@ -207,6 +207,19 @@ def alt_modes(B: int, L: int, headline: str):
         res[prec] = {"value": round(3 * B / (time.perf_counter() - t0), 2), "unit": "responses/s",
                      "first_token_ms": round(ftm, 2), "phase_ms": {k: round(v, 2) for k, v in e.last_phase_ms().items()},
                      "note": ALT_NOTES[prec]}
+        if prec == "fp8":
+            # BASELINE configs[4]'s per-GPU batch (fp8 weights, B = 128, max_len 64): its single-GPU leg, 2 passes
+            b1, b2, bi = synth.make_batch(128)
+            b1d, b2d, bid = e._f32(b1), e._f32(b2), e._i32(bi)
+            e.generate(b1d, b2d, bid, max_len=L, stop_id=0, ignore_stop=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                e.generate(b1d, b2d, bid, max_len=L, stop_id=0, ignore_stop=True)
+            torch.cuda.synchronize()
+            res["fp8_b128"] = {"batch": 128, "value": round(2 * 128 / (time.perf_counter() - t0), 2), "unit": "responses/s",
+                               "phase_ms": {k: round(v, 2) for k, v in e.last_phase_ms().items()},
+                               "note": "BASELINE configs[4] (fp8, B = 128, max_len 64) on one GPU; decode weights stay fp32 (DESIGN 6b)"}
         e.close()
     return res
 

@@ -557,16 +557,19 @@ def test_wrapper_end_to_end_from_wav_files(synth_sd, tmp_path):
 
 
 def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
-    """BASELINE configs[2] per-rank shape: top_p=0.8, temperature=1.0, max_len=300 (context 389..689).
-    The sampling arguments change nothing (reference wrapper.py:220-232 never removes the arg-max); the first tokens
-    are the reference golden ones; a long run extends a short one; other top_p / temperature values give the same ids."""
-    a1, a2, ids = synth.make_batch(4)
+    """BASELINE configs[2] at its exact per-rank shape: 32 examples, top_p=0.8, temperature=1.0, max_len=300 (context 389..689).
+    Rows 0 and 1 equal the REFERENCE's own 300-step run of those two examples (late.npz), all 32 rows equal the reference's
+    32-example run for its 8 steps (b32.npz); the sampling arguments change nothing (reference wrapper.py:220-232 never
+    removes the arg-max); a long run extends a short one."""
+    a1, a2, ids = synth.make_batch(32)
     t300, lens, n, _ = engine.generate(a1, a2, ids, max_len=300, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
-    assert t300.shape == (4, 300) and n == 300 and (t300 >= 0).all() and (t300 < 49152).all()
-    g = np.load(os.path.join(golden_dir, "gen.npz"))
-    assert np.array_equal(t300[:2, : g["tokens"].shape[1]], g["tokens"])
-    t64, *_ = engine.generate(a1, a2, ids, max_len=64, top_p=0.3, temperature=0.7, stop_id=0, ignore_stop=True)
-    assert np.array_equal(t64, t300[:, :64])
+    assert t300.shape == (32, 300) and n == 300 and (t300 >= 0).all() and (t300 < 49152).all()
+    late = np.load(os.path.join(golden_dir, "late.npz"))
+    assert np.array_equal(t300[:2], late["tokens"])
+    b32 = np.load(os.path.join(golden_dir, "b32.npz"))
+    assert np.array_equal(t300[:, : b32["tokens"].shape[1]], b32["tokens"])
+    t64, *_ = engine.generate(a1[:4], a2[:4], ids[:4], max_len=64, top_p=0.3, temperature=0.7, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t64, t300[:4, :64])
     # reference stop rule at this length: stop id := a token row 2 first produces late in the run
     row = t300[2]
     k = next(i for i in range(200, 300) if row[i] not in row[:i])
