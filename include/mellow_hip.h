@@ -171,6 +171,10 @@ int         mellow_prof_get(mellow_engine_t* e, int i, int64_t* launches, double
 int         mellow_last_phase_ms(mellow_engine_t* e, float* encode_ms, float* prefill_ms, float* decode_ms);
 /* decode steps (counting the prefill's token) the last mellow_generate call enqueued: *out_steps, or *out_steps + 1 */
 int         mellow_last_steps_enqueued(mellow_engine_t* e);
+/* Diagnostic: how many times the last mellow_generate call repacked the still-running rows into fewer 32-row blocks
+ * (reference-semantics mode, B > 32: a block's kernels return at once when all of ITS rows have produced the stop id; rows
+ * migrate between blocks so that this happens as early as the number of running rows allows). */
+int         mellow_last_row_repacks(mellow_engine_t* e);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

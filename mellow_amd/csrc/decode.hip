@@ -185,11 +185,16 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     __shared__ float snew_s[3];
 
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
-    MELLOW_BLK_EXIT(b >> 5)
+    int row = b;                  // the example whose KV pages this slot reads and extends (slot == example unless rows migrate)
+    if (BLK) {
+        const int live = a.blk_live[b >> 5];
+        if (a.row_of_slot) row = a.row_of_slot[b];
+        if (live == 0 || row < 0) return;       // the block has stopped / the slot is empty (workgroup-uniform)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tmax = a.Tmax;
-    float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
-    float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    float* kpage = k_cache + ((int64_t)row * 3 + g) * Tmax * 64;
+    float* vpage = v_cache + ((int64_t)row * 3 + g) * Tmax * 64;
     const int sub = lane >> 4, quad = lane & 15;   // lane -> (key sub, dim quad): a wave instruction = 4 keys x 64 dims
 
     // ===== ONE round trip, every load independent and straight-line: position word, RMS partials, qkv slabs,
@@ -725,8 +730,10 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
     __shared__ int bi[4];
     __shared__ int tok_s;
     const int b = blockIdx.x, tid = threadIdx.x;
-    // a row whose whole block has stopped computes nothing any more, but still takes part in the step's arrival count
-    const bool dead = lp.blk_live && lp.blk_live[b >> 5] == 0;      // workgroup-uniform; written by an EARLIER launch
+    // a slot whose whole block has stopped (or that is empty after a repack) computes nothing any more, but still takes part
+    // in the step's arrival count
+    const int row = lp.row_of_slot ? lp.row_of_slot[b] : b;         // the example in this slot
+    const bool dead = (lp.blk_live && lp.blk_live[b >> 5] == 0) || row < 0;      // workgroup-uniform; written by an EARLIER launch
     float best = -INFINITY;
     int idx = 0x7fffffff;
     if (!dead) {
@@ -756,9 +763,9 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
             if (!dead) {
                 const int max_len = lp.params[0], stop_id = lp.params[1];
                 const int step = *a.d_pos - lp.T0 + 1;
-                if (step >= 0 && step < max_len) lp.out_tokens[(int64_t)b * max_len + step] = idx;
-                if (idx == stop_id && lp.seen_stop[b] == 0) {
-                    lp.seen_stop[b] = 1;
+                if (step >= 0 && step < max_len) lp.out_tokens[(int64_t)row * max_len + step] = idx;
+                if (idx == stop_id && lp.seen_stop[row] == 0) {
+                    lp.seen_stop[row] = 1;
                     atomicAdd(lp.n_seen, 1);
                     if (lp.blk_left && atomicSub(lp.blk_left + (b >> 5), 1) == 1) lp.blk_live[b >> 5] = 0;   // from the NEXT step on
                 }
@@ -783,6 +790,71 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
             reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
         }
     }
+}
+
+// Row migration (reference stop rule, more than one 32-row block).  One workgroup, after the step's arg-max: the rows that
+// have not produced the stop id yet are counted; if they fit into fewer 32-row blocks than are live, they are packed (stable)
+// into the lowest slots: their next-step residual rows move, row_of_slot is rewritten, the emptied blocks' live words are
+// cleared.  A row's arithmetic does not depend on its slot (MFMA rows are independent, every reduction is per row), so the
+// tokens are unchanged; rows that had already stopped are dropped (their texts are cut at the stop id anyway).
+__global__ __launch_bounds__(1024) void dec_compact_kernel(const DecArgs a, int B, const LoopArgs lp) {
+    __shared__ int src_of[1024];           // new slot -> old slot
+    __shared__ int row_new[1024];
+    __shared__ int wsum[16];
+    __shared__ int n_act_s, n_live_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (B + 31) >> 5;
+    int row = -1, active = 0;
+    if (tid < B) {
+        row = lp.row_of_slot[tid];
+        active = row >= 0 && lp.blk_live[tid >> 5] != 0 && lp.seen_stop[row] == 0;
+    }
+    // exclusive prefix sum of `active` over the slots: ballot inside a wave, then over the 16 waves
+    const unsigned long long m = __ballot(active);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    if (tid == 0) {
+        int live = 0;
+        for (int k = 0; k < nblk; ++k) live += lp.blk_live[k] != 0;
+        n_live_s = live;
+    }
+    src_of[tid] = -1;
+    row_new[tid] = -1;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < 16; ++w) n += wsum[w];
+        n_act_s = n;
+    }
+    __syncthreads();
+    const int n_act = n_act_s;
+    if ((n_act + 31) / 32 >= n_live_s) return;            // repacking would not empty a block (workgroup-uniform)
+    if (active) { src_of[base + before] = tid; row_new[base + before] = row; }
+    __syncthreads();
+    // move the residual rows, 7 destination slots (7 x 144 float4 = 1008 threads) at a time in increasing order: a destination
+    // is never above its source and sources only grow, so a chunk can only overwrite sources of chunks already done
+    float4* x = reinterpret_cast<float4*>(a.xmidF);
+    for (int d0 = 0; d0 < n_act; d0 += 7) {
+        const int d = d0 + tid / 144, c = tid % 144;
+        const bool mv = tid < 1008 && d < n_act && src_of[d] != d;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mv) v = x[f32_idx(src_of[d] >> 5, 72, src_of[d] & 31, c * 4)];
+        __syncthreads();
+        if (mv) x[f32_idx(d >> 5, 72, d & 31, c * 4)] = v;
+        __syncthreads();
+    }
+    if (tid < B) lp.row_of_slot[tid] = row_new[tid];
+    if (tid < 32) {
+        const int left = tid < nblk ? min(max(n_act - 32 * tid, 0), 32) : 0;
+        lp.blk_left[tid] = left;
+        lp.blk_live[tid] = left > 0;
+    }
+    if (tid == 0) *lp.n_compactions += 1;
+}
+void launch_dec_compact(const DecArgs& a, int B, const LoopArgs& loop, hipStream_t s) {
+    hipLaunchKernelGGL(dec_compact_kernel, dim3(1), dim3(1024), 0, s, a, B, loop);
 }
 
 // rows -> residual stream (row-major + F32-layout): src row b = in[row_of(b)]

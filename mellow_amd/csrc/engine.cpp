@@ -150,12 +150,16 @@ struct mellow_engine {
     int32_t *d_tokens = nullptr, *d_step = nullptr, *d_pos = nullptr, *d_seen = nullptr, *d_nseen = nullptr;
     int32_t *d_arrive = nullptr, *d_ticket = nullptr, *d_params = nullptr;   // loop bookkeeping words (LoopArgs)
     int32_t *d_blk_left = nullptr, *d_blk_live = nullptr;                    // per-row-block early exit (32 blocks max)
+    int32_t *d_row_of_slot = nullptr, *d_ncompact = nullptr;                 // row migration (kernels.h, DecArgs::row_of_slot)
+    int last_compactions = 0;
     const void* graph_blk = nullptr;                                         // DecArgs::blk_live the graphs were captured with
+    const void* graph_rows = nullptr;                                        // DecArgs::row_of_slot likewise
     unsigned long long* h_progress = nullptr;  // mapped host word the arg-max kernel publishes (ticket << 32 | rows stopped) to
     unsigned long long* d_progress = nullptr;  // its device alias
     std::map<std::pair<int, int>, float*> resample_banks;   // (orig, new) gcd-reduced -> device polyphase bank [klen][new]
     int32_t h_params[2] = {0, 0};              // staging of d_params {max_len, stop id}
     int32_t h_blk[64] = {0};                   // staging of d_blk_left[32] | d_blk_live[32]
+    std::vector<int32_t> h_ident;              // staging of d_row_of_slot
     int last_steps_enqueued = 0;               // decode steps (incl. the prefill's token) the last generate call enqueued
     Buf out_tok;                               // engine-owned token record [rows][max_len] (stable address: graph-safe)
     int kv_B = 0, kv_Tmax = 0;                // current page geometry
@@ -776,6 +780,8 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     e->d_blk_left = e->d_tokens + 1040;
     e->d_blk_live = e->d_tokens + 1072;
     e->d_seen = e->d_tokens + 2048;
+    e->d_row_of_slot = e->d_tokens + 3072;
+    e->d_ncompact = e->d_tokens + 1029;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped));
     *e->h_progress = 0;
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_progress), e->h_progress, 0));
@@ -1055,6 +1061,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
         a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
+        a.row_of_slot = nullptr;
         // (and the logits store off: the taps mellow_lm_prefill / mellow_lm_decode_step read dlogits, generation does not)
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
@@ -1102,6 +1109,7 @@ static LoopArgs loop_args(mellow_engine* e) {
     lp.params = e->d_params; lp.seen_stop = e->d_seen; lp.n_seen = e->d_nseen; lp.arrive = e->d_arrive; lp.ticket = e->d_ticket;
     lp.host_progress = e->d_progress; lp.T0 = e->cfg.prefix_len;
     if (e->da.blk_live) { lp.blk_left = e->d_blk_left; lp.blk_live = e->d_blk_live; }
+    if (e->da.row_of_slot) { lp.row_of_slot = e->d_row_of_slot; lp.n_compactions = e->d_ncompact; }
     return lp;
 }
 
@@ -1114,7 +1122,8 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
       launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
     { ProfScope ps(e, PF_MISC, 0, 0);
       launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? loop_args(e) : LoopArgs(),
-                        e->stream); }
+                        e->stream);
+      if (rec && e->da.row_of_slot) launch_dec_compact(e->da, B, loop_args(e), e->stream); }
     return 0;
 }
 
@@ -1474,10 +1483,20 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     e->da.logits = nullptr;             // generation needs the arg-max candidates only: no 6 MB logits store per step
     e->da.blk_live = (!ignore_stop && e->da.RB > 1) ? e->d_blk_live : nullptr;
     static const bool dev_dead = getenv("MELLOW_DEV_DEAD_BLOCKS") != nullptr;    // developer probe: launch-chain floor of a step
+    static const bool no_migrate = getenv("MELLOW_NO_ROW_MIGRATION") != nullptr;   // developer A/B: block exit without repacking
+    e->da.row_of_slot = nullptr;
     if (dev_dead) {
         e->da.blk_live = e->d_blk_live;
         HIPCHK(hipMemsetAsync(e->d_blk_left, 0, 64 * sizeof(int32_t), s));
     } else if (e->da.blk_live) {
+        if (!no_migrate && B <= 1024) {
+            std::vector<int32_t> ident(1024);
+            for (int i = 0; i < 1024; ++i) ident[i] = i < B ? i : -1;
+            e->h_ident = ident;       // kept alive until the copy has run
+            HIPCHK(hipMemcpyAsync(e->d_row_of_slot, e->h_ident.data(), 1024 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemsetAsync(e->d_ncompact, 0, sizeof(int32_t), s));
+            e->da.row_of_slot = e->d_row_of_slot;
+        }
         for (int rb = 0; rb < 32; ++rb) {
             const int left = B - 32 * rb;
             e->h_blk[rb] = left <= 0 ? 0 : (left > 32 ? 32 : left);
@@ -1498,7 +1517,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // captured once per (B, page geometry, buffers) and replayed; max_len and the stop id are read from d_params
     const bool graph = e->use_graph && !e->prof_on && max_len > 1;
     if (graph && (!e->step_exec || e->step_exec_B != B || e->step_exec_Tmax != e->kv_Tmax || e->graph_out_tok != e->out_tok.p ||
-                  e->graph_blk != e->da.blk_live)) {
+                  e->graph_blk != e->da.blk_live || e->graph_rows != e->da.row_of_slot)) {
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
         if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         hipGraph_t gr = nullptr;
@@ -1519,7 +1538,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         if (ce8 != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce8));
         HIPCHK(hipGraphInstantiate(&e->step_exec8, gr, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(gr));
-        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tok = e->out_tok.p; e->graph_blk = e->da.blk_live;
+        e->step_exec_B = B; e->step_exec_Tmax = e->kv_Tmax; e->graph_out_tok = e->out_tok.p; e->graph_blk = e->da.blk_live; e->graph_rows = e->da.row_of_slot;
     }
     int steps_done = 1;   // token 0 came from the prefill
     double first_ms = -1.0;
@@ -1577,6 +1596,8 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         }
     }
     e->last_steps_enqueued = steps_done;
+    e->last_compactions = 0;
+    if (e->da.row_of_slot) HIPCHK(hipMemcpy(&e->last_compactions, e->d_ncompact, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out_steps) *out_steps = ref_steps;
     if (out_len)
         for (int b = 0; b < B; ++b) {
@@ -1589,6 +1610,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
 }
 
 int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_enqueued : -1; }
+int mellow_last_row_repacks(mellow_engine_t* e) { return e ? e->last_compactions : -1; }
 
 int mellow_prof_enable(mellow_engine_t* e, int on) {
     if (!e) return fail("null engine");

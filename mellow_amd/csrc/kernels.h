@@ -121,6 +121,11 @@ struct DecArgs {
     // per-row-block early exit (reference stop rule, batches of more than one 32-row block): blk_live[rb] == 0 once every
     // row of block rb has produced the stop id -- its workgroups return at once.  Null = never skip (one block / fixed length).
     const int32_t* blk_live = nullptr;
+    // row migration (same mode): row_of_slot[s] = the example whose state lives in batch slot s, or -1 for an empty slot.  The
+    // slot addresses everything a step computes (activations, slabs); the example addresses what persists (its KV pages, its
+    // token record, its stop flag).  dec_compact_kernel repacks the rows that are still running into the lowest slots
+    // whenever that empties a whole 32-row block.
+    const int32_t* row_of_slot = nullptr;
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
@@ -145,6 +150,8 @@ struct LoopArgs {
     int32_t* ticket = nullptr;           // arg-max launches since the start of the call
     int32_t* blk_left = nullptr;         // [row blocks] rows of the block that have not produced the stop id yet
     int32_t* blk_live = nullptr;         // [row blocks] cleared by the row that brings blk_left to 0 (DecArgs::blk_live)
+    int32_t* row_of_slot = nullptr;      // [rows] example of each batch slot (DecArgs::row_of_slot); null: slot == example
+    int32_t* n_compactions = nullptr;    // repacks done during the call (diagnostic)
     unsigned long long* host_progress = nullptr;   // mapped host memory
     int T0 = 0;                          // prefix length
 };
@@ -152,6 +159,9 @@ struct LoopArgs {
 // write_x it gathers embed[token] as the next step's residual stream
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
                        const LoopArgs& loop, hipStream_t s);
+// after the arg-max of a step (early-exit mode only): if the rows that have not produced the stop id yet fit into fewer 32-row
+// blocks than are live, move them (their next-step residual rows) to the lowest slots, rewrite row_of_slot / blk_left / blk_live
+void launch_dec_compact(const DecArgs& a, int B, const LoopArgs& loop, hipStream_t s);
 // residual stream <- rows of `in`: row_ids[b] (embedding gather) or, when row_ids == null, row b*T_last + T_last-1
 void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
                           int n_src /* rows of `in` that row_ids may address */, hipStream_t s);

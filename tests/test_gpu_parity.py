@@ -373,6 +373,36 @@ def test_batch32_matches_reference(engine, golden_dir):
         assert logits.argmax(-1).cpu().tolist() == g["tokens"][:, i].tolist()
 
 
+@pytest.mark.parametrize("n_rows,n_early,min_repacks", [(64, 5, 1), (96, 6, 2), (40, 4, 1)])
+def test_rows_migrate_between_blocks_when_most_have_stopped(engine_f32, golden_dir, n_rows, n_early, min_repacks):
+    """SURVEY 8f-3, row compaction: 64 / 96 / 40 rows in 32-row blocks, n_early of every 8 of them copies of examples that produce the stop id at
+    steps 2..6 (tests/golden/b32.npz: the reference's own tokens for examples 4, 9, 14, 22, 24, 26), spread over BOTH blocks.
+    Once they have stopped, the 24 running rows fit into one block: they are repacked into block 0 and block 1's kernels
+    return at once.  Every row's tokens up to its own stop are those of the free-running reference tokens, rows that never
+    stop run to the end, and the repack really happened (`mellow_last_row_repacks`)."""
+    g = np.load(os.path.join(golden_dir, "b32.npz"))
+    stop = 42274
+    early = [4, 9, 14, 22, 24, 26]                   # first stop id at steps 3, 3, 3, 2, 6, 5
+    late = [0, 1, 3, 7, 8, 12]                       # no stop id within the golden's 8 steps
+    rows = []
+    for i in range(n_rows):                          # n_early early rows, then late ones, through all the blocks
+        rows.append(early[(i // 8 * 5 + i % 8) % 6] if i % 8 < n_early else late[(i // 8 * 3 + i % 8) % 6])
+    a1, a2, ids = synth.make_examples(rows)
+    L = int(g["steps"])
+    toks, lens, n, _ = engine_f32.generate(a1, a2, ids, max_len=L, stop_id=stop)
+    assert engine_f32.last_row_repacks() >= min_repacks
+    ref = g["tokens"]
+    for i, ex in enumerate(rows):
+        want = ref[ex]
+        hit = np.flatnonzero(want == stop)
+        k = int(hit[0]) if hit.size else L
+        assert int(lens[i]) == min(k, n), (i, ex, lens[i], k)
+        m = min(k + 1, n)
+        assert np.array_equal(toks[i, :m], want[:m]), (i, ex, toks[i], want)
+        assert ((toks[i, m:n] == -1) | (toks[i, m:n] == want[m:n])).all()       # later columns: never computed, or the free run
+    assert n == L                                    # the late rows never stop: the loop runs to max_len
+
+
 def test_ragged_batch3_matches_reference(engine, golden_dir):
     """B = 3 run by the reference itself (tests/golden/ragged3.npz): tokens exact, third row's prefix and logits in tolerance."""
     g = np.load(os.path.join(golden_dir, "ragged3.npz"))
