@@ -57,6 +57,19 @@ __device__ __forceinline__ float4 ldg_nt(const float4* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 #endif
 }
+// Decode weights in e4m3 (BASELINE config 5, `W8` variants of the five GEMM kernels): the SAME slot order as the fp32 layouts
+// (one float4 slot = one 4-byte word of four e4m3 values), one scale per packed weight row, applied to the reduced output.
+// The values are widened to fp32 in registers and multiplied on the fp32 matrix pipe: the activations stay fp32.
+template <bool W8>
+__device__ __forceinline__ float4 ldw(const float* __restrict__ Wp, int64_t slot) {
+    if constexpr (W8) {
+        const uint32_t u = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Wp) + slot);
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(u, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(u, true);
+        return make_float4(lo[0], lo[1], hi[0], hi[1]);
+    } else {
+        return ldg_nt(reinterpret_cast<const float4*>(Wp) + slot);
+    }
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -81,8 +94,9 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 #endif
 constexpr int QW = MELLOW_QKV_WAVES;                 // compute waves: 3 x 3 k-tiles or 9 x 1
 constexpr int QKV_THREADS = QW * 64 < 256 ? 256 : QW * 64;
-template <int KCD, bool BLK, bool FIRST>
-__global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+template <int KCD, bool BLK, bool FIRST, bool W8>
+__global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
+                                                              const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[QW * 16 * 64];
     __shared__ float ssq_s[QW * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,13 +115,13 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
     MELLOW_BLK_EXIT(rb)      // every row of this block has stopped (workgroup-uniform)
     if (wave < QW) {
         const int k8_0 = (kc * QW + wave) * KPW;
-        const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+        const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
         const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-            w[i] = ldg_nt(wp + i * 64);
+            w[i] = ldw<W8>(Wp, wslot + i * 64);
             x[i] = xb[i * 64];
 #pragma unroll
             for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
@@ -157,6 +171,10 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
         v[j] = sacc;
     }
     const int n = nt * 32 + 8 * gq + 4 * hh;
+    if (W8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= wscale[n + j];
+    }
     if (n < 960)
         *reinterpret_cast<float4*>(a.pq + ((int64_t)kc * a.rows + rb * 32 + mm) * 960 + n) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -395,15 +413,16 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 // waves per workgroup: 12 x 3 k16-tiles = the 36 tiles exactly (16 x 3 left 12 empty slots whose loads were still issued:
 // +1.1 ms of decode per 63 steps, measured on one box with tools/ab_build.sh)
 constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
-template <bool BLK>
-__global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+template <bool BLK, bool W8>
+__global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16,
+                                                                  const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
     constexpr int K16 = 36, TPW = (K16 + OP_WAVES - 1) / OP_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
     MELLOW_BLK_EXIT(rb)
     const int ml = lane & 15;
-    const float4* wp = reinterpret_cast<const float4*>(Wp16) + (int64_t)nt * K16 * 64 + lane;
+    const int64_t wslot = (int64_t)nt * K16 * 64 + lane;
     // epilogue operand issued up front: thread (m, nq) of the 16 x 16 tile owns 4 consecutive columns
     const int em = (tid >> 2) & 15, enq = tid & 3;
     const int64_t erow = (int64_t)rb * 32 + mh * 16 + em;
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = wave + OP_WAVES * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
-        w[i] = ldg_nt(wp + (int64_t)tc * 64);
+        w[i] = ldw<W8>(Wp16, wslot + (int64_t)tc * 64);
         if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
@@ -459,6 +478,10 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
         for (int wv = 0; wv < OP_WAVES; ++wv)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += red[(wv * 4 + r) * 64 + src_lane];
+        if (W8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= wscale[nt * 16 + enq * 4 + r];
+        }
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
         const int k = nt * 16 + enq * 4;
         reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, mh * 16 + em, k)] = y;
@@ -480,23 +503,23 @@ enum { OUT_LOGITS = 1 };
 #define MELLOW_LM_WAVES 8     // 8 x 9 k-tiles: 53.45 vs 54.35 ms of decode per 63 steps with 4 x 18 (6 / 9 / 12 waves: 54.1 / 54.1 / 53.7)
 #endif
 constexpr int LM_WAVES = MELLOW_LM_WAVES;
-template <int OUT, bool BLK>
+template <int OUT, bool BLK, bool W8>
 __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
-                                                        const float* __restrict__ XF, int N) {
+                                                        const float* __restrict__ XF, int N, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[LM_WAVES * 16 * 64];
     constexpr int KPW = 72 / LM_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, rb = blockIdx.z;
     MELLOW_BLK_EXIT(rb)
     const int k8_0 = wave * KPW;
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
     float4 w[KPW], x[KPW];
     const bool dbg = tid == 0 && nt == 0 && rb == 0;
     const int dslot = 5;
     kstamp(dslot, 0, dbg);
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) { w[i] = ldg_nt(wp + i * 64); x[i] = xp[i * 64]; }
+    for (int i = 0; i < KPW; ++i) { w[i] = ldw<W8>(Wp, wslot + i * 64); x[i] = xp[i * 64]; }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(dslot, 1, dbg);
     f32x16 acc;
@@ -522,6 +545,10 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs 
     }
     {
         const int n = nt * 32 + 8 * gq + 4 * hh;
+        if (W8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= wscale[n + j];
+        }
         const int64_t row = (int64_t)rb * 32 + mm;
         if (epi && a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
         // best (value, lowest index) of this 32-column tile per row (torch.argmax tie rule)
@@ -563,8 +590,9 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs 
 #define MELLOW_GU_WAVES 4
 #endif
 constexpr int GU_WAVES = MELLOW_GU_WAVES;
-template <bool BLK>
-__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16) {
+template <bool BLK, bool W8>
+__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16,
+                                                                     const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[GU_WAVES * 8 * 64];
     constexpr int K16 = 36, TPW = K16 / GU_WAVES;
     static_assert(TPW * GU_WAVES == K16, "waves must divide the 36 k16-tiles");
@@ -572,14 +600,14 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
     const int nt = blockIdx.x, rb = blockIdx.y;
     MELLOW_BLK_EXIT(rb)
     const int t0 = wave * TPW;
-    const float4* wp = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * K16 + t0) * 64 + lane;
+    const int64_t wslot = ((int64_t)nt * K16 + t0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
     // epilogue thread (m = tid>>1, q = tid&1), tid < 64: its row's 36 sum-of-squares partials, issued up front
     const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + ((tid >> 1) & 31)) * 40);
     float4 w[TPW], x0[TPW], x1[TPW], s4[9];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        w[i] = ldg_nt(wp + i * 64);
+        w[i] = ldw<W8>(Wp16, wslot + i * 64);
         x0[i] = xp[(i * 2) * 64];
         x1[i] = xp[(i * 2 + 1) * 64];
     }
@@ -625,6 +653,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
                 gv += red[(wv * 8 + rbase + r) * 64 + gl];
                 uv += red[(wv * 8 + rbase + r) * 64 + ul];
             }
+            if (W8) { gv *= wscale[nt * 16 + 4 * q + r]; uv *= wscale[nt * 16 + 8 + 4 * q + r]; }     // packed tile rows
             h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
         }
         // hidden unit k = 8*nt + 4*q + r: down k-tile nt, F32-layout lane' = m + 32*q
@@ -643,22 +672,23 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
 // 53.0-53.2 with 6 x 4, 8 x 3 or 12 x 2 (same box, tools/ab_build.sh)
 constexpr int DN_WAVES = MELLOW_DOWN_WAVES;
 static_assert(DN_WAVES >= 4 && 192 % (8 * DN_WAVES) == 0, "the epilogue needs 256 threads; waves must divide the k-tiles");
-template <bool BLK>
-__global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p) {
+template <bool BLK, bool W8>
+__global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
+                                                                 const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
     constexpr int KPW = 192 / (DEC_KC_DOWN * DN_WAVES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x, kc = blockIdx.y, rb = blockIdx.z;
     MELLOW_BLK_EXIT(rb)
     const int k8_0 = (kc * DN_WAVES + wave) * KPW;
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
     const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
     kstamp(4, 0, dbg);
     float4 w[KPW], h4[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        w[i] = ldg_nt(wp + i * 64);
+        w[i] = ldw<W8>(Wp, wslot + i * 64);
         h4[i] = hp[i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -685,6 +715,10 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
             v[j] = sacc;
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
+        if (W8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= wscale[n + j];
+        }
         reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = make_float4(v[0], v[1], v[2], v[3]);
     }
     kstamp(4, 4, dbg);
@@ -871,19 +905,28 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------
-// BLK = per-row-block early exit compiled in (a.blk_live != null): two instantiations, chosen on the host
+// BLK = per-row-block early exit compiled in (a.blk_live != null); W8 = e4m3 weights (wscale != null): chosen on the host
 #define MELLOW_LAUNCH_BLK(KERNEL, GRID, BLOCK, ...)                                                               \
     do {                                                                                                         \
         if (a.blk_live) hipLaunchKernelGGL((KERNEL<true>), GRID, BLOCK, 0, s, __VA_ARGS__);                       \
         else hipLaunchKernelGGL((KERNEL<false>), GRID, BLOCK, 0, s, __VA_ARGS__);                                 \
     } while (0)
-void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStream_t s) {
+#define MELLOW_LAUNCH_BLK_W8(KERNEL, GRID, BLOCK, ...)                                                            \
+    do {                                                                                                         \
+        if (a.blk_live && wscale) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);     \
+        else if (a.blk_live) hipLaunchKernelGGL((KERNEL<true, false>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);          \
+        else if (wscale) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);              \
+        else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);                         \
+    } while (0)
+void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStream_t s, const float* wscale) {
     const dim3 grid(30, DEC_KC_QKV, a.RB);
     // the first qkv launch of a step (a.first) always starts from a materialised x (kcd == 0); later ones sum the down slabs
 #define MELLOW_QKV(KCD, FIRST)                                                                              \
     do {                                                                                                    \
-        if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p);   \
-        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p);             \
+        if (a.blk_live && wscale) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, true>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
+        else if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, false>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);        \
+        else if (wscale) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, true>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
+        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, false>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);                       \
     } while (0)
     if (kcd == 0 && a.first) MELLOW_QKV(0, true);
     else if (kcd == 0) MELLOW_QKV(0, false);
@@ -895,14 +938,14 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream
     MELLOW_LAUNCH_BLK(dec_attn_kernel, dim3(3, a.rows, DEC_TS), dim3(DA_WAVES * 64), a, k_cache, v_cache);
 }
 int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
-void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), a, Wp16);
+void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
+    MELLOW_LAUNCH_BLK_W8(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), a, Wp16);
 }
-void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), a, Wp16);
+void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
+    MELLOW_LAUNCH_BLK_W8(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), a, Wp16);
 }
-void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), a, Wp, K8p);
+void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s, const float* wscale) {
+    MELLOW_LAUNCH_BLK_W8(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), a, Wp, K8p);
 }
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s) {
     if (kcd == 0) {
@@ -913,9 +956,48 @@ void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipSt
         else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, false>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
     }
 }
-void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s) {
-    if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true>), dim3(vocab / 32, 1, a.RB), dim3(LM_WAVES * 64), 0, s, a, Wp, K8p, a.xnF, vocab);
-    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false>), dim3(vocab / 32, 1, a.RB), dim3(LM_WAVES * 64), 0, s, a, Wp, K8p, a.xnF, vocab);
+void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale) {
+    const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
+    if (a.blk_live && wscale) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, true>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, false>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (wscale) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, true>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, false>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+}
+// fp32 packed decode weight (P-layout: 32 rows per tile, or P16: 16 rows per tile; `slots` float4 slots per tile) -> one
+// 4-byte word of four e4m3 values per slot + one scale per packed row (amax / 448): one workgroup per tile
+__global__ __launch_bounds__(256) void pack_dec_fp8_kernel(const float4* __restrict__ Wp, int slots, int rows, uint32_t* __restrict__ out,
+                                                           float* __restrict__ scale) {
+    __shared__ unsigned amax_s[32];
+    __shared__ float inv_s[32];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) amax_s[tid] = 0u;
+    __syncthreads();
+    const float4* src = Wp + (int64_t)tile * slots;
+    for (int i = tid; i < slots; i += 256) {
+        const float4 v = src[i];
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        atomicMax(&amax_s[(i & 63) & (rows - 1)], __float_as_uint(m));          // non-negative floats order like their bit patterns
+    }
+    __syncthreads();
+    if (tid < rows) {
+        const float am = __uint_as_float(amax_s[tid]);
+        const float sc = am > 0.f ? am / 448.0f : 1.0f;
+        scale[(int64_t)tile * rows + tid] = sc;
+        inv_s[tid] = 1.0f / sc;
+    }
+    __syncthreads();
+    for (int i = tid; i < slots; i += 256) {
+        const float4 v = src[i];
+        const float inv = inv_s[(i & 63) & (rows - 1)];
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * inv, v.y * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * inv, v.w * inv, w, true);
+        out[(int64_t)tile * slots + i] = (uint32_t)w;
+    }
+}
+void launch_pack_dec_fp8(const float* Wp, int tiles, int slots_per_tile, int rows_per_tile, void* out, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(pack_dec_fp8_kernel, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float4*>(Wp), slots_per_tile,
+                       rows_per_tile, reinterpret_cast<uint32_t*>(out), scale);
 }
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
                        const LoopArgs& loop, hipStream_t s) {

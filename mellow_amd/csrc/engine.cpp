@@ -98,6 +98,10 @@ struct LMLayerW {
     Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
     float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
     float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, tile = 8 gate rows + the 8 matching up rows
+    // fp8 mode: e4m3 copies of the four decode operands in the same slot order (one 4-byte word per float4 slot) and one
+    // scale per packed weight row (launch_pack_dec_fp8)
+    float *qkv8 = nullptr, *qkv_sc = nullptr, *o8 = nullptr, *o_sc = nullptr, *gu8 = nullptr, *gu_sc = nullptr, *dn8 = nullptr,
+          *dn_sc = nullptr;
     float *in_ln, *post_ln;
 };
 
@@ -176,6 +180,9 @@ struct mellow_engine {
     // fp8 GEMM mode (BASELINE config 5): every packed weight with KP % 64 == 0 also gets a P8 copy + per-row scales,
     // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
     bool fp8 = false;
+    bool fp8_decode = false;                     // fp8 mode: the decode kernels read e4m3 weights too (off: MELLOW_FP8_DECODE=0)
+    bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (off: MELLOW_FP8_PREFILL=0, a test isolating the decode weights)
+    float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
     int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
     bool decode_only_weight = false;             // set while packing weights only the decode kernels read: no bf16x3 / fp8 copy
     std::unordered_map<const float*, void*> bf_w;   // fp32 packed pointer -> PB copy
@@ -541,6 +548,15 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
     *out = p;
     return 0;
 }
+// e4m3 copy of a packed decode weight (tiles x slots float4 slots, `rows` packed rows per tile)
+static int make_dec_fp8(mellow_engine* e, const float* Wp, int tiles, int slots, int rows, float** out8, float** scale) {
+    CHK(dev_alloc(e, out8, (size_t)tiles * slots));
+    CHK(dev_alloc(e, scale, (size_t)tiles * rows));
+    launch_pack_dec_fp8(Wp, tiles, slots, rows, *out8, *scale, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
 static int make_packed16(mellow_engine* e, const float* w, int N, int K, float** out) {
     if (N % 16 || K % 16) return fail("P16 packing needs N and K multiples of 16");
     float* d0 = nullptr;
@@ -696,6 +712,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         e->decode_only_weight = true;                 // the lm_head runs in the decode kernels only (last position)
         CHK(make_packed(e, get(e, k)->f(), nullptr, V, H, &e->lm_head));
         e->decode_only_weight = false;
+        if (e->fp8_decode) CHK(make_dec_fp8(e, e->lm_head.p, e->lm_head.NP / 32, (e->lm_head.KP / 8) * 64, 32, &e->head8, &e->head_sc));
     }
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const std::string p = L + "model.layers." + std::to_string(l) + ".";
@@ -743,6 +760,12 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                 CHK(make_packed16(e, il.data(), 2 * I, H, &w.gu16));
             }
             CHK(make_packed16(e, get(e, p + "self_attn.o_proj.weight")->f(), H, 576, &w.o16));
+        }
+        if (e->fp8_decode) {
+            CHK(make_dec_fp8(e, w.qkv_f.p, w.qkv_f.NP / 32, (w.qkv_f.KP / 8) * 64, 32, &w.qkv8, &w.qkv_sc));
+            CHK(make_dec_fp8(e, w.o16, H / 16, (576 / 16) * 64, 16, &w.o8, &w.o_sc));
+            CHK(make_dec_fp8(e, w.gu16, 2 * I / 16, (H / 16) * 64, 16, &w.gu8, &w.gu_sc));
+            CHK(make_dec_fp8(e, w.down.p, w.down.NP / 32, (w.down.KP / 8) * 64, 32, &w.dn8, &w.dn_sc));
         }
         e->layers.push_back(w);
     }
@@ -811,7 +834,7 @@ static int run_gemm(mellow_engine* e, const GemmArgs& a) {
             return 0;
         }
     }
-    if (e->fp8 && a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
+    if (e->fp8 && e->fp8_prefill && a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
         auto it = e->fp8_w.find(a.Wp);
         if (it != e->fp8_w.end()) {
             // quantise the activation rows, then the fp8 MFMA GEMM (same epilogue); profiled as one launch of the family
@@ -1119,7 +1142,8 @@ static int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArg
     { ProfScope ps(e, PF_NORM, 0, (double)(pending_kcd + 2) * Bp * 576 * 4);
       launch_dec_final_norm(e->da, e->final_norm, pending_kcd, e->stream); }
     { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * e->cfg.vocab_size, 576.0 * e->cfg.vocab_size * 4);
-      launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
+      if (e->head8) launch_dec_lm_head(e->da, e->head8, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream, e->head_sc);
+      else launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
     { ProfScope ps(e, PF_MISC, 0, 0);
       launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? loop_args(e) : LoopArgs(),
                         e->stream);
@@ -1214,15 +1238,19 @@ static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int 
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
         a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 960.0, 576.0 * 960.0 * 4);
-          launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
+          if (w.qkv8) launch_dec_qkv(a, w.qkv8, w.qkv_f.KP / 8, kcd, s, w.qkv_sc);
+          else launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
         { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
           launch_dec_attn(e->da, kc, vc, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
-          launch_dec_oproj(e->da, w.o16, s); }
+          if (w.o8) launch_dec_oproj(e->da, w.o8, s, w.o_sc);
+          else launch_dec_oproj(e->da, w.o16, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
-          launch_dec_gateup(e->da, w.gu16, s); }
+          if (w.gu8) launch_dec_gateup(e->da, w.gu8, s, w.gu_sc);
+          else launch_dec_gateup(e->da, w.gu16, s); }
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
-          launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
+          if (w.dn8) launch_dec_down(e->da, w.dn8, w.down.KP / 8, s, w.dn_sc);
+          else launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
     }
     return 0;
 }
@@ -1826,6 +1854,10 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     if (mode != MELLOW_PRECISION_F32 && mode != MELLOW_PRECISION_FP8 && mode != MELLOW_PRECISION_F32X3)
         return fail("unknown precision mode %d", mode);
     e->fp8 = mode == MELLOW_PRECISION_FP8;
+    // developer / test knobs of the fp8 mode (read here, per engine): which half of the path reads e4m3 weights
+    const char *fd = getenv("MELLOW_FP8_DECODE"), *fp = getenv("MELLOW_FP8_PREFILL");
+    e->fp8_decode = e->fp8 && !(fd && fd[0] == '0');
+    e->fp8_prefill = !(fp && fp[0] == '0');
     e->f32x3_terms = 0;
     if (mode == MELLOW_PRECISION_F32X3) {
         // six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64

@@ -129,14 +129,17 @@ struct DecArgs {
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
-void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s);
+// The five GEMM launchers take an optional `wscale`: when non-null, the weight pointer addresses the e4m3 copy of the same
+// layout (launch_pack_dec_fp8: one 4-byte word per float4 slot) and wscale holds one factor per packed weight row
+void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s, const float* wscale = nullptr);
+void launch_pack_dec_fp8(const float* Wp, int tiles, int slots_per_tile, int rows_per_tile, void* out, float* scale, hipStream_t s);
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s);
 int dec_attn_chunk_groups();   // 4-key groups one attention workgroup covers per pass
-void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s);
-void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s);
-void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s);
+void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale = nullptr);
+void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s, const float* wscale = nullptr);
+void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s);
-void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s);
+void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale = nullptr);
 // Generation-loop bookkeeping that lives on the device (reference wrapper.py:232-249), written by the arg-max kernel:
 // the token is recorded at column (*d_pos - T0 + 1) of out_tokens, rows that produced the stop id are counted once, and
 // the LAST row to arrive publishes (step ticket << 32 | rows that have stopped) to a host-visible word, so the host
