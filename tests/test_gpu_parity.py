@@ -84,7 +84,7 @@ def test_frontend_logmel(engine, batch2, oracle_taps, golden_dir):
     _close(lmb[:, ::10], g["logmel_bn_sub"], rel=5e-6, atol=1e-5, name="logmel_bn vs golden")
 
 
-def test_encoder_taps(engine, batch2, oracle_taps, golden_dir):
+def test_encoder_taps(engine, batch2, oracle_taps, golden_dir, synth_sd):
     a1, _, _ = batch2
     _, t = oracle_taps
     g = np.load(os.path.join(golden_dir, "enc10.npz"))
@@ -92,7 +92,20 @@ def test_encoder_taps(engine, batch2, oracle_taps, golden_dir):
     try:
         enc = engine.encode(a1)
         pw = engine.tap("power").reshape(2, 1001, 544)
-        _close(pw[:, :, :513], t["power"][:, 0], rel=2e-6, name="power")
+        if engine.precision == "f32":
+            _close(pw[:, :, :513], t["power"][:, 0], rel=2e-6, name="power")
+        else:
+            # f32x3 runs the STFT on exact bf16 splits: against the oracle's fp32 conv1d it is a DIFFERENT fp32 summation order of
+            # 1024-term dot products (measured 2.5e-6 of max, bound 4e-6); against an fp64 STFT of the same weights it must be at
+            # least as close as the oracle's own fp32 arithmetic is
+            _close(pw[:, :, :513], t["power"][:, 0], rel=4e-6, name="power")
+            from oracle import mellow_oracle as O
+            kr, ki = O.ENC + "spectrogram_extractor.stft.conv_real.weight", O.ENC + "spectrogram_extractor.stft.conv_imag.weight"
+            with torch.no_grad():
+                p64 = O.stft_power({kr: synth_sd[kr].double(), ki: synth_sd[ki].double()}, torch.from_numpy(a1).double())[:, 0]
+            err_hip = float((pw[:, :, :513].cpu().double() - p64).abs().max())
+            err_ref = float((t["power"][:, 0].double() - p64).abs().max())
+            assert err_hip <= err_ref, (err_hip, err_ref)
         assert float(pw[:, :, 513:].abs().max()) == 0.0     # padded bins come from zero weight rows
         patch = engine.tap("patch").reshape(2, 4096, 96)
         _close(patch, t["patch"], name="patch")
