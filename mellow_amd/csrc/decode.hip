@@ -236,7 +236,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     float4 sl4[DEC_KC_QKV], sq4[2];
     if (tid < 80) {
 #pragma unroll
-        for (int s = 0; s < DEC_KC_QKV; ++s) sl4[s] = *reinterpret_cast<const float4*>(prow + (int64_t)s * a.rows * 960);
+        for (int s = 0; s < DEC_KC_QKV; ++s)
+            sl4[s] = (MELLOW_DA_ABL & 4) ? make_float4(0.1f * s, 0.2f, 0.3f, 0.4f) : *reinterpret_cast<const float4*>(prow + (int64_t)s * a.rows * 960);
         sq4[0] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[0];
         sq4[1] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[1];
     }
@@ -244,12 +245,20 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const int gbeg = sp * a.gs;                                   // groups of 4 keys
     const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + a.gs;
     float4 k4[DA_G], v4[DA_G];
+#ifndef MELLOW_DA_ABL
+#define MELLOW_DA_ABL 0      // developer ablation (wrong results, timing only): 1 no K/V page loads, 2 no score / softmax / PV loop, 4 no slab prologue loads
+#endif
 #pragma unroll
     for (int u = 0; u < DA_G; ++u) {
         const int gi = gbeg + wave + u * DA_WAVES;
         const int tc = min(gi * 4 + sub, Tmax - 1);               // inside the page; validity is decided later
-        k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
-        v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
+        if (MELLOW_DA_ABL & 1) {
+            k4[u] = make_float4(0.01f * tc, 0.02f, 0.03f, 0.04f);
+            v4[u] = make_float4(0.01f, 0.02f * tc, 0.03f, 0.04f);
+        } else {
+            k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
+            v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 1, dbg);
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int g0 = gbeg + wave; g0 < gend; g0 += DA_WAVES * DA_G) {
+    for (int g0 = gbeg + wave; g0 < ((MELLOW_DA_ABL & 2) ? gbeg : gend); g0 += DA_WAVES * DA_G) {
         if (g0 != gbeg + wave) {           // later chunks (only for contexts beyond 448 keys): reload
 #pragma unroll
             for (int u = 0; u < DA_G; ++u) {
