@@ -185,6 +185,9 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
 //     per-wave online softmax over an interleaved set of 4-key groups; partial (m, l, o) per split.
 //     Split sp owns key groups [sp*gs, (sp+1)*gs) (the last split: everything from sp*gs on, plus the new key).
 // ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_DA_ABL
+#define MELLOW_DA_ABL 0      // developer ablation (wrong results, timing only): 1 no K/V page loads, 2 no score / softmax / PV loop, 4 no slab prologue loads
+#endif
 #ifndef MELLOW_DA_WAVES
 #define MELLOW_DA_WAVES 8
 #define MELLOW_DA_G 7
@@ -245,9 +248,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const int gbeg = sp * a.gs;                                   // groups of 4 keys
     const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + a.gs;
     float4 k4[DA_G], v4[DA_G];
-#ifndef MELLOW_DA_ABL
-#define MELLOW_DA_ABL 0      // developer ablation (wrong results, timing only): 1 no K/V page loads, 2 no score / softmax / PV loop, 4 no slab prologue loads
-#endif
 #pragma unroll
     for (int u = 0; u < DA_G; ++u) {
         const int gi = gbeg + wave + u * DA_WAVES;
