@@ -119,7 +119,8 @@ int  mellow_prefix(mellow_engine_t* e, const float* audio1, const float* audio2,
  * (may be NULL). */
 int  mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int reserve, float* logits);
 /* A15 decode step: append embed_tokens(token_ids) (wrapper.py:237) at the next position and return the
- * new last-position logits.  token_ids dev i32 [B]; logits dev [B][vocab] (may be NULL). */
+ * new last-position logits.  token_ids dev i32 [B]; logits dev [B][vocab] (may be NULL).  Continues the state of the last
+ * mellow_lm_prefill; a mellow_generate or mellow_lm_forward_logits call in between ends that state (error). */
 int  mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* logits);
 /* lm.model.embed_tokens(ids) (decoder.py:47,64-66; wrapper.py:237): token_ids dev i32 [n] -> out dev [n][hidden]. */
 int  mellow_embed_tokens(mellow_engine_t* e, const int32_t* token_ids, int n, float* out);

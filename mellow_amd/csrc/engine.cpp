@@ -1625,6 +1625,8 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
         }
     }
     e->last_steps_enqueued = steps_done;
+    e->cur_B = 0;      // the decode state of a generate call (no logits store, early-exit words) is not a base for the step taps:
+                       // mellow_lm_decode_step needs a mellow_lm_prefill of its own
     e->last_compactions = 0;
     if (e->da.row_of_slot) HIPCHK(hipMemcpy(&e->last_compactions, e->d_ncompact, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out_steps) *out_steps = ref_steps;

@@ -349,6 +349,8 @@ def test_all_position_forward_matches_reference(engine, batch2, golden_dir):
     gg = np.load(os.path.join(golden_dir, "gen.npz"))
     toks, _, _, _ = engine.generate(a1, a2, ids, max_len=8, stop_id=-1)
     assert np.array_equal(toks, gg["tokens"][:, :8])
+    with pytest.raises(EngineError):                     # a generate call's decode state is not a base for the step tap either
+        engine.lm_decode_step(np.zeros(2, dtype=np.int64))
     with pytest.raises(EngineError):
         engine.lm_forward_logits(pre[:1], from_pos=389)
     with pytest.raises(IndexError):
