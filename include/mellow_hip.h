@@ -176,6 +176,9 @@ int         mellow_last_steps_enqueued(mellow_engine_t* e);
  * (reference-semantics mode, B > 32: a block's kernels return at once when all of ITS rows have produced the stop id; rows
  * migrate between blocks so that this happens as early as the number of running rows allows). */
 int         mellow_last_row_repacks(mellow_engine_t* e);
+/* 1 when this engine runs the STFT (A1, htsat.py:864) as a 1024-point FFT per frame instead of the DFT GEMM: f32x3 mode and a
+ * checkpoint whose conv_real / conv_imag weights are window[n] * cos / sin(2 pi k n / 1024) to 1e-6 (checked at finalize). */
+int         mellow_stft_is_fft(mellow_engine_t* e);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

@@ -124,6 +124,9 @@ struct mellow_engine {
 
     // encoder weights
     Packed dft, mel;
+    // f32x3 mode: the STFT as a real FFT when the checkpoint's conv weights are window[n] * cos / sin(2 pi k n / 1024) (checked
+    // element by element at load time); fft_win == nullptr: the DFT GEMM on the checkpoint's weights
+    float *fft_win = nullptr, *fft_tw1 = nullptr, *fft_tw2 = nullptr;
     float *bn_alpha = nullptr, *bn_beta = nullptr;
     float *pe_w = nullptr, *pe_b = nullptr, *pe_nw = nullptr, *pe_nb = nullptr;
     std::vector<SwinBlockW> blocks[4];
@@ -588,6 +591,36 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(expect_shape(get(e, kr), kr, {kNfreq, 1, kNfft}));
         CHK(expect_shape(get(e, ki), ki, {kNfreq, 1, kNfft}));
         CHK(make_packed(e, get(e, kr)->f(), get(e, ki)->f(), kNfreq, kNfft, &e->dft));
+        static const bool no_fft = getenv("MELLOW_STFT_FFT") && getenv("MELLOW_STFT_FFT")[0] == '0';
+        if (e->f32x3_terms && !no_fft && kNfft == 1024) {
+            // the reference builds these weights as window[n] * cos / -sin(2 pi k n / N) (torchlibrosa STFT, frozen parameters);
+            // a checkpoint that holds anything else keeps the GEMM.  Row k = 0 of the real part IS the window.
+            const float *wr = get(e, kr)->f(), *wi = get(e, ki)->f();
+            double wmax = 0.0, dev = 0.0;
+            for (int n = 0; n < kNfft; ++n) wmax = std::max(wmax, (double)fabsf(wr[n]));
+            for (int k = 0; k < kNfreq; ++k)
+                for (int n = 0; n < kNfft; ++n) {
+                    const double a = 2.0 * M_PI * (double)((int64_t)k * n % kNfft) / kNfft, w0 = wr[n];
+                    dev = std::max(dev, fabs((double)wr[(size_t)k * kNfft + n] - w0 * cos(a)));
+                    dev = std::max(dev, fabs(fabs((double)wi[(size_t)k * kNfft + n]) - fabs(w0 * sin(a))));
+                }
+            if (wmax > 0.0 && dev <= 1e-6 * wmax) {
+                std::vector<float> t1((size_t)16 * 64 * 2), t2((size_t)4 * 16 * 2);
+                for (int k1 = 0; k1 < 16; ++k1)
+                    for (int b = 0; b < 64; ++b) {
+                        const double a = -2.0 * M_PI * (double)(b * k1) / 1024.0;
+                        t1[((size_t)k1 * 64 + b) * 2] = (float)cos(a); t1[((size_t)k1 * 64 + b) * 2 + 1] = (float)sin(a);
+                    }
+                for (int d = 0; d < 4; ++d)
+                    for (int q = 0; q < 16; ++q) {
+                        const double a = -2.0 * M_PI * (double)(d * q) / 64.0;
+                        t2[((size_t)d * 16 + q) * 2] = (float)cos(a); t2[((size_t)d * 16 + q) * 2 + 1] = (float)sin(a);
+                    }
+                CHK(upload(e, &e->fft_win, wr, kNfft));
+                CHK(upload(e, &e->fft_tw1, t1.data(), t1.size()));
+                CHK(upload(e, &e->fft_tw2, t2.data(), t2.size()));
+            }
+        }
         const std::string km = E + "logmel_extractor.melW";
         CHK(expect_shape(get(e, km), km, {kNfreq, kMel}));
         std::vector<float> mt((size_t)kMel * kNfreq);
@@ -893,7 +926,11 @@ static int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samp
         ProfScope ps(e, PF_MISC, 0, 2.0 * n * plen * 4);
         launch_reflect_pad(wav, n, n_samples, e->wpad.p, plen, kNfft / 2, s);
     }
-    {   // A1: STFT power as DFT GEMM on the checkpoint's conv weights (htsat.py:864)
+    if (e->fft_win) {   // A1 as a real FFT (f32x3 mode, weights verified to be the windowed DFT basis): 5 N log2 N flops per frame
+        ProfScope ps(e, PF_GEMM, 5.0 * kNfft * 10.0 * M, (double)M * (kNfft + 544) * 4);
+        ps.r.M = M; ps.r.N = 544; ps.r.K = kNfft; ps.r.epi = 400;
+        launch_stft_fft_power(e->wpad.p, frames, plen, kHop, M, e->fft_win, e->fft_tw1, e->fft_tw2, e->power.p, s);
+    } else {   // A1: STFT power as DFT GEMM on the checkpoint's conv weights (htsat.py:864)
         GemmArgs g;
         g.A = e->wpad.p; g.a_mode = A_FRAMES; g.fpc = frames; g.clip_stride = plen; g.hop = kHop;
         g.M = M; g.K = kNfft; g.Wp = e->dft.p; g.Nw = e->dft.Nw; g.N = 544; g.C = e->power.p; g.ldc = 544; g.epi = EPI_POWER;
@@ -1642,6 +1679,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
 
 int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_enqueued : -1; }
 int mellow_last_row_repacks(mellow_engine_t* e) { return e ? e->last_compactions : -1; }
+int mellow_stft_is_fft(mellow_engine_t* e) { return e && e->fft_win ? 1 : 0; }
 
 int mellow_prof_enable(mellow_engine_t* e, int on) {
     if (!e) return fail("null engine");

@@ -192,6 +192,10 @@ void launch_layernorm(const float* in, float* out, int M, int C, const float* w,
 // patch merging gather + LN(4C): in [n][R*R][C] -> out [n][(R/2)^2][4C]
 void launch_merge_layernorm(const float* in, float* out, int n, int R, int C, const float* w, const float* b,
                             hipStream_t s);
+// A1 as a 1024-point FFT per frame (stft_fft.hip): power[m][0..512] = |DFT(win * frame m)|^2, columns 513..543 zero.  win [1024];
+// tw1 [16][64] complex = exp(-2 pi i b k1 / 1024), tw2 [4][16] complex = exp(-2 pi i d e / 64)
+void launch_stft_fft_power(const float* wpad, int fpc, int64_t clip_stride, int hop, int M, const float* win, const float* tw1,
+                           const float* tw2, float* power, hipStream_t s);
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s);
 // the same numbers, written pre-split in APB order (C % 16 == 0) for the x3q GEMM
 void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s);

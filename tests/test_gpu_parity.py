@@ -128,6 +128,60 @@ def test_encoder_taps(engine, batch2, oracle_taps, golden_dir, synth_sd):
         engine.enable_taps(False)
 
 
+def test_stft_runs_as_fft_only_on_windowed_dft_weights(synth_sd):
+    """f32x3 mode runs A1 (htsat.py:864) as a 1024-point FFT per frame when -- and only when -- the checkpoint's conv_real /
+    conv_imag weights are window[n] * cos / sin(2 pi k n / 1024) (checked element by element at load).  (a) the FFT's power
+    spectrum against an fp64 STFT built from the SAME weights, on noise, digital silence, an impulse and a full-scale square
+    wave: 1e-6 of the maximum (an fp32 FFT is more accurate than a 1024-term fp32 dot product); (b) the exact-fp32 engine keeps
+    the GEMM; (c) a checkpoint with ONE perturbed basis element falls back to the GEMM on its own weights and follows them."""
+    from mellow_amd.engine import Engine
+    from oracle import mellow_oracle as O
+    kr, ki = O.ENC + "spectrogram_extractor.stft.conv_real.weight", O.ENC + "spectrogram_extractor.stft.conv_imag.weight"
+    n = 320000
+    rng = np.random.default_rng(5)
+    sq = np.where((np.arange(n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    imp = np.zeros(n, dtype=np.float32)
+    imp[777] = 1.0
+    wav = np.stack([rng.standard_normal(n).astype(np.float32) * 0.3, np.zeros(n, dtype=np.float32), imp, sq])
+
+    def power_of(engine):
+        engine.enable_taps(True)
+        try:
+            engine.logmel(wav)
+            return engine.tap("power").reshape(4, 1001, 544).cpu().double()
+        finally:
+            engine.enable_taps(False)
+
+    def p64_of(sd):
+        with torch.no_grad():
+            return O.stft_power({kr: sd[kr].double(), ki: sd[ki].double()}, torch.from_numpy(wav).double())[:, 0]
+
+    e3 = Engine(device=0, precision="f32x3")
+    e3.load_state_dict(synth_sd)
+    assert e3.stft_is_fft()
+    pw, p64 = power_of(e3), p64_of(synth_sd)
+    assert float(pw[:, :, 513:].abs().max()) == 0.0
+    for i in range(4):
+        scale = float(p64[i].max())
+        assert float((pw[i, :, :513] - p64[i]).abs().max()) <= 1e-6 * scale + 1e-30, i
+    assert float(pw[1].abs().max()) == 0.0                                    # silence stays exactly zero
+    e0 = Engine(device=0)
+    e0.load_state_dict(synth_sd)
+    assert not e0.stft_is_fft()
+    sd = dict(synth_sd)
+    w = sd[kr].clone()
+    w[200, 0, 300] += 0.25                                                    # no longer a windowed DFT basis
+    sd[kr] = w
+    e3b = Engine(device=0, precision="f32x3")
+    e3b.load_state_dict(sd)
+    assert not e3b.stft_is_fft()
+    pb, pb64 = power_of(e3b), p64_of(sd)
+    assert float((pb[0, :, :513] - pb64[0]).abs().max()) <= 4e-6 * float(pb64[0].max())
+    assert float((pb64[0, :, 200] - p64[0, :, 200]).abs().max()) > 1e-3 * float(p64[0].max())     # the perturbation is visible
+    for e in (e3, e0, e3b):
+        e.close()
+
+
 def test_prefix(engine, batch2, oracle_taps, golden_dir):
     a1, a2, ids = batch2
     oprefix, _ = oracle_taps

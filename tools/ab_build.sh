@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; flags=$2
 out=mellow_amd/lib/libmellow_hip_$name.so
 tmp=$(mktemp -d)
-for f in gemm_f32.hip gemm_fp8.hip gemm_bf16x3.hip decode.hip prefill_attn.hip encoder.hip engine.cpp; do
+for f in gemm_f32.hip gemm_fp8.hip gemm_bf16x3.hip decode.hip prefill_attn.hip encoder.hip stft_fft.hip engine.cpp; do
   extra=""
   case $f in gemm_bf16x3.hip|gemm_fp8.hip|prefill_attn.hip|encoder.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -x hip $flags $extra -c mellow_amd/csrc/$f -o $tmp/$f.o &

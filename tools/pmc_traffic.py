@@ -18,7 +18,7 @@ def family(path, counter):
     n, tot = 0, 0.0
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and ("gemm_f32_kernel" in r["Kernel_Name"] or "gemm_x3p_kernel" in r["Kernel_Name"] or "gemm_x3q_kernel" in r["Kernel_Name"]
-                                             or "gemm_bf16x3f_kernel" in r["Kernel_Name"]):
+                                             or "gemm_bf16x3f_kernel" in r["Kernel_Name"] or "stft_fft_power_kernel" in r["Kernel_Name"]):
             n += 1
             tot += float(r["Counter_Value"])
     return n, tot
@@ -28,7 +28,7 @@ nf, fetch = family(sys.argv[1], "FETCH_SIZE")
 nw, write = family(sys.argv[2], "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
 out = {
-    "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill) / gemm_x3p_kernel / gemm_bf16x3f_kernel (f32x3 mode) + gemm_f32_kernel (all instances)",
+    "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill) / gemm_x3p_kernel / gemm_bf16x3f_kernel (f32x3 mode) + gemm_f32_kernel (all instances) + stft_fft_power_kernel (the STFT of the f32x3 mode)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py "
               "(2 encoder+prefill passes at B=32, in the `precision` mode below); reduced with tools/pmc_traffic.py",
     "source_sha16": kernel_source_sha16(),
