@@ -220,6 +220,21 @@ def b32_case(args, model, t0):
                         logits_max=L.max(-1).values.numpy())
 
 
+def b64_tail_case(args, model, t0):
+    """examples 32..63 (the second half of the north_star's 64-example batch) through the reference: 4 greedy steps + prefix"""
+    a1, a2, ids = synth.make_batch(32, first=32)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
+                                                        "input": {"input_ids": torch.from_numpy(ids)}})
+        _, toks, logits_log = ref_generate_tokens(model, prefix, 4, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    L = torch.stack(logits_log)
+    top2 = torch.topk(L, 2, dim=-1).values
+    print(f"b64 tail tokens ({time.time() - t0:.1f}s): min top-2 gap {float((top2[..., 0] - top2[..., 1]).min()):.4f}")
+    np.savez_compressed(os.path.join(args.out, "b64tail.npz"), first=32, steps=4, tokens=toks,
+                        prefix_sub=prefix[:, ::13, ::9].numpy(), logits_max=L.max(-1).values.numpy())
+
+
 FWD_ANSWER_LEN = 12
 FWD_FROM = 380
 
@@ -295,7 +310,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32 "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64 "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -392,6 +407,8 @@ def main():
         forward_case(args, model, a1t, a2t, idst, prefix, t0)
     if "b32" in only or (not only and not args.skip_long):
         b32_case(args, model, t0)
+    if "b64" in only or (not only and not args.skip_long):
+        b64_tail_case(args, model, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
     print(f"done ({time.time() - t0:.1f}s)")

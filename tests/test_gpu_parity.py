@@ -472,6 +472,30 @@ def test_rows_migrate_between_blocks_when_most_have_stopped(engine_f32, golden_d
     assert n == L                                    # the late rows never stop: the loop runs to max_len
 
 
+def test_batch64_matches_reference(engine, golden_dir):
+    """The north_star's batch of 64 in ONE call (two 32-row blocks): rows 0..31 against the reference's 32-example run
+    (b32.npz), rows 32..63 against its run of examples 32..63 (b64tail.npz) -- tokens equal, prefixes and the per-step maximum
+    logit (teacher-forced) within the fp32 path's tolerances."""
+    g1 = np.load(os.path.join(golden_dir, "b32.npz"))
+    g2 = np.load(os.path.join(golden_dir, "b64tail.npz"))
+    a1, a2, ids = synth.make_batch(64)
+    steps = int(g2["steps"])
+    ref = np.concatenate([g1["tokens"][:, :steps], g2["tokens"]])
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=steps, stop_id=-1)
+    bad = np.argwhere(toks != ref)
+    assert n == steps and bad.size == 0, f"first divergence from the reference at (row, step) {bad[0].tolist()}"
+    pre = engine.prefix(a1, a2, ids)
+    _close(pre[:32, ::7, ::5], g1["prefix_sub"], name="prefix rows 0..31")
+    _close(pre[32:, ::13, ::9], g2["prefix_sub"], name="prefix rows 32..63")
+    logits = engine.lm_prefill(pre, reserve=steps)
+    for i in range(steps):
+        if i:
+            logits = engine.lm_decode_step(ref[:, i - 1])
+        want = np.concatenate([g1["logits_max"][i], g2["logits_max"][i]])
+        _close(logits.max(-1).values, want, rel=0, atol=3e-3, name=f"max logit of 64 rows at step {i}")
+        assert logits.argmax(-1).cpu().tolist() == ref[:, i].tolist()
+
+
 def test_ragged_batch3_matches_reference(engine, golden_dir):
     """B = 3 run by the reference itself (tests/golden/ragged3.npz): tokens exact, third row's prefix and logits in tolerance."""
     g = np.load(os.path.join(golden_dir, "ragged3.npz"))
