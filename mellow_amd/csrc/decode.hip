@@ -422,20 +422,30 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 // waves per workgroup: 12 x 3 k16-tiles = the 36 tiles exactly (16 x 3 left 12 empty slots whose loads were still issued:
 // +1.1 ms of decode per 63 steps, measured on one box with tools/ab_build.sh)
 constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
-template <bool BLK, bool W8>
+// rows per workgroup: 16 (two halves of a 32-row block, 72 workgroups) or 8 (four quarters, 144 workgroups: the MFMA tile still
+// has 16 batch columns, eight of them zero, but a workgroup pulls half the attention partials -- its body is bound by the
+// bytes one CU has to ingest)
+// Chosen per launch: 8 rows for a single row block (B <= 32: 52.8 -> 52.2 ms of decode per 63 steps), 16 rows otherwise (at
+// B = 64 the 288 eight-row workgroups no longer fit the 256 CUs: 76.3 -> 78.5 ms).  MELLOW_OPROJ_ROWS forces one form.
+template <bool BLK, bool W8, int OP_ROWS>
 __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16,
                                                                   const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
     constexpr int K16 = 36, TPW = (K16 + OP_WAVES - 1) / OP_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x, rb = blockIdx.y >> 1, mh = blockIdx.y & 1;
+    constexpr int PARTS = 32 / OP_ROWS;                     // workgroups per 32-row block
+    const int nt = blockIdx.x, rb = blockIdx.y / PARTS, part = blockIdx.y % PARTS;
+    const int mh = OP_ROWS == 16 ? part : part >> 1;        // which 16-row half the MFMA tile covers
     MELLOW_BLK_EXIT(rb)
     const int ml = lane & 15;
+    const bool lrow = OP_ROWS == 16 || (ml >> 3) == (part & 1);          // this lane's batch row belongs to the workgroup
     const int64_t wslot = (int64_t)nt * K16 * 64 + lane;
     // epilogue operand issued up front: thread (m, nq) of the 16 x 16 tile owns 4 consecutive columns
     const int em = (tid >> 2) & 15, enq = tid & 3;
+    const bool erow_ok = OP_ROWS == 16 || (em >> 3) == (part & 1);
     const int64_t erow = (int64_t)rb * 32 + mh * 16 + em;
-    const float4 xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
+    float4 xres = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (erow_ok) xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
 
     float4 w[TPW], os[TPW][DEC_TS];
     float ms[TPW][DEC_TS], ls[TPW][DEC_TS];
@@ -448,9 +458,12 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
         for (int s = 0; s < DEC_TS; ++s) {
-            ms[i][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
-            ls[i][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
-            os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
+            ms[i][s] = 0.f; ls[i][s] = 1.f; os[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);     // rows of another workgroup: x = 0
+            if (lrow) {
+                ms[i][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
+                ls[i][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
+                os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 && erow_ok) {
         // columns n = 4*enq + r live in registers r = 0..3 of lane em + 16*enq
         const int src_lane = em + 16 * enq;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -948,7 +961,21 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream
 }
 int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
-    MELLOW_LAUNCH_BLK_W8(dec_oproj_kernel, dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), a, Wp16);
+#ifdef MELLOW_OPROJ_ROWS
+    const int rows = MELLOW_OPROJ_ROWS;
+#else
+    const int rows = a.RB == 1 ? 8 : 16;
+#endif
+#define MELLOW_OPROJ(BLKV, W8V)                                                                                             \
+    do {                                                                                                                    \
+        if (rows == 8) hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 8>), dim3(36, 4 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);  \
+        else hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 16>), dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);           \
+    } while (0)
+    if (a.blk_live && wscale) MELLOW_OPROJ(true, true);
+    else if (a.blk_live) MELLOW_OPROJ(true, false);
+    else if (wscale) MELLOW_OPROJ(false, true);
+    else MELLOW_OPROJ(false, false);
+#undef MELLOW_OPROJ
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
     MELLOW_LAUNCH_BLK_W8(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), a, Wp16);

@@ -89,7 +89,10 @@ double gemm_flops(const GemmArgs& a);
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------
 // split factors are compile-time so that partial-sum ("slab") loads are fully unrolled and issued together
 constexpr int DEC_KC_QKV = 8;    // qkv: 72 k-tiles = 8 chunks x 3 waves x 3  (30 x 8 = 240 workgroups <= 256 CUs)
-constexpr int DEC_KC_DOWN = 8;   // down: 192 k-tiles = 8 chunks x 6 waves x 4
+#ifndef MELLOW_DEC_KC_DOWN
+#define MELLOW_DEC_KC_DOWN 8
+#endif
+constexpr int DEC_KC_DOWN = MELLOW_DEC_KC_DOWN;   // down: 192 k-tiles = 8 chunks x 4 waves x 6
 #ifndef MELLOW_DEC_TS
 #define MELLOW_DEC_TS 2
 #endif
