@@ -260,10 +260,24 @@ def main():
                          "e4m3 GEMMs in the encoder's Swin linears and LM prefill; a different metric line)")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the supplementary fp8 / f32x3 measurements")
     ap.add_argument("--no-b64", action="store_true", help="skip the supplementary batch-64 (north_star) measurement")
+    ap.add_argument("--preset", choices=("configs1", "configs2", "configs4"), default=None,
+                    help="BASELINE.json configs[i] per-GPU shapes: configs1 = the headline (batch 32, max_len 64; the default), "
+                         "configs2 = batch 32/GPU (256 over 8 GPUs), max_len 300, configs4 = fp8 weights, batch 128/GPU, max_len 64")
     ap.add_argument("--inflight", type=int, default=0,
                     help="also measure N engine contexts pipelining the same batches on this GPU (supplementary "
                          "'pipelined' object; never the headline value)")
     args = ap.parse_args()
+    if args.preset == "configs2":
+        args.batch, args.max_len = 32, 300
+    elif args.preset == "configs4":
+        args.batch, args.max_len, args.precision = 128, 64, "fp8"
+    # every MELLOW_* variable this process saw goes into the line; developer probes that change the answers (MELLOW_DEV_*,
+    # honoured only by -DMELLOW_DEVPROBE builds) are refused outright: a number measured under one is not a measurement
+    mellow_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MELLOW_")}
+    bad = [k for k in mellow_env if k.startswith("MELLOW_DEV_")]
+    if bad:
+        print(f"bench.py: refusing to run with developer probes set: {bad}", file=sys.stderr)
+        sys.exit(2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -398,7 +412,7 @@ def main():
         peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32X3_TFLOPS if args.precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
         t_roof = DENSE_GFLOP_PER_RESPONSE / (peak * 1e3) * B + dec_bytes / (PEAK_HBM_GBS * 1e9)
         out = {
-            "metric": "audio-pair responses/sec (v0 167M, 2x10s clips, max_len=64, greedy)" +
+            "metric": f"audio-pair responses/sec (v0 167M, 2x10s clips, max_len={L}, greedy)" +
                       (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else "") +
                       (" [exact-fp32-MFMA mode]" if args.precision == "f32" else ""),
             "value": round(value, 2), "unit": "responses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -410,7 +424,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"v0 167M, batch {B}/GPU, 2x10s 32kHz synthetic clips + 16-token prompts, max_len={L}, "
                                    f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",
-                       "global_batch": n_gpus * B, "max_len": L, "parallelism": f"dp{n_gpus}"},
+                       "global_batch": n_gpus * B, "max_len": L, "parallelism": f"dp{n_gpus}", "preset": args.preset or "configs1"},
+            "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+            "env": mellow_env,
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
             "roofline": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"

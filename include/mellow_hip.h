@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define MELLOW_ABI_VERSION 1
+/* 2: out_tokens may hold -1 (never-computed steps), first_token_ms is host wall-clock time, a decode step needs a prefill of
+ *    its own after mellow_generate / mellow_lm_forward_logits, the optional "mellow.rope_cos/sin" tensors, new symbols */
+#define MELLOW_ABI_VERSION 2
 
 typedef struct mellow_engine mellow_engine_t;
 
@@ -67,7 +69,15 @@ void mellow_engine_destroy(mellow_engine_t* e);
 /* Hand one checkpoint tensor to the engine under its reference state_dict key, e.g.
  * "audio_encoder.base.htsat.layers.0.blocks.1.attn.qkv.weight".  `data` may be a host or a device
  * pointer; the engine copies / re-tiles it into its own arena before returning.  Keys the inference
- * path never reads are accepted and ignored (returns 0).  Unknown keys fail. */
+ * path never reads are accepted and ignored (returns 0).  Unknown keys fail.
+ *
+ * Two OPTIONAL tensors that are not checkpoint keys: "mellow.rope_cos" and "mellow.rope_sin", f32 [max_positions][head_dim/2],
+ * the rotary tables cos / sin(position * inv_freq).  The reference never stores them: transformers' LlamaRotaryEmbedding
+ * recomputes them with torch on every forward, so their last bit is whatever torch's vectorised cos/sin give on the host it
+ * runs on.  A binding that wants the engine to use EXACTLY the numbers its own torch would produce computes them the HF way
+ *  and loads them here before finalize.  Without them the engine builds the tables itself
+ * (mellow_host_rope_tables: fp32 inv_freq and angle as in HF, cos/sin evaluated in double and rounded to fp32 -- within
+ * 1 ulp of torch's, tests/test_abi_cpu.py); both paths are parity-tested for 300 decode steps. */
 int  mellow_engine_load_tensor(mellow_engine_t* e, const char* key, const void* data,
                                const int64_t* shape, int ndim, int dtype);
 /* Verifies that every tensor the hot path reads has been loaded (strict, like load_state_dict at
@@ -203,6 +213,10 @@ int  mellow_host_window_map(int R, int shift, int32_t* out);
 /* packs a row-major [N][K] fp32 matrix into the engine's MFMA fragment order:
  * out host f32 [NP/32][KP/8][64][4] with NP = roundup(N,npad), KP = roundup(K,32), zero padded. */
 int  mellow_host_pack_weight(const float* w, int N, int K, int npad, float* out, int64_t out_capacity);
+/* the rotary tables the engine builds when "mellow.rope_cos/sin" are not loaded (transformers LlamaRotaryEmbedding:
+ * inv_freq = 1 / theta^(2i/head_dim) and angle = position * inv_freq in fp32; cos / sin correctly rounded to fp32).
+ * cos_out / sin_out host f32 [max_pos][head_dim/2]. */
+int  mellow_host_rope_tables(float theta, int head_dim, int max_pos, float* cos_out, float* sin_out);
 
 #ifdef __cplusplus
 }

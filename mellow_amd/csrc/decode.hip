@@ -195,9 +195,14 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
 constexpr int DA_WAVES = MELLOW_DA_WAVES;
 constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chunk covers 2 * DA_WAVES * DA_G * 4 = 448 keys
 
-template <bool BLK>
+// FUSED: the producer was dec_qkv2_kernel (the previous layer's down projection and this layer's q/k/v in one launch): the
+// projected values arrive as Q2_NPQ slabs, and x_new = x_mid + sum of the Q2_HC down slabs is formed HERE (the 144 float4 of the
+// row, by every workgroup of the row: its sum of squares is the RMS statistic; the (kv head 0, split 0) workgroup also writes the
+// row for the o_proj's residual).  !FUSED: the producer was dec_qkv_kernel (first layer of a step: 8 slabs + its own statistic).
+template <bool BLK, bool FUSED>
 __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
                                                                   float* __restrict__ v_cache) {
+    __shared__ float ssq_part[3];
     __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
     __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
     __shared__ __attribute__((aligned(16))) float xs[320];               // q (3 x 64) | k | v before RoPE, RMS-scaled
@@ -236,13 +241,24 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const int r = tid < 80 ? tid : 0;
     const int pcol = r < 48 ? (3 * g + (r >> 4)) * 64 + 4 * (r & 15) : r < 64 ? 576 + g * 64 + 4 * (r - 48) : 768 + g * 64 + 4 * (r - 64);
     const float* prow = a.pq + (int64_t)b * 960 + pcol;
-    float4 sl4[DEC_KC_QKV], sq4[2];
+    constexpr int NPQ = FUSED ? Q2_NPQ : DEC_KC_QKV;
+    float4 sl4[NPQ], sq4[2];
     if (tid < 80) {
 #pragma unroll
-        for (int s = 0; s < DEC_KC_QKV; ++s)
+        for (int s = 0; s < NPQ; ++s)
             sl4[s] = (MELLOW_DA_ABL & 4) ? make_float4(0.1f * s, 0.2f, 0.3f, 0.4f) : *reinterpret_cast<const float4*>(prow + (int64_t)s * a.rows * 960);
-        sq4[0] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[0];
-        sq4[1] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[1];
+        if (!FUSED) {
+            sq4[0] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[0];
+            sq4[1] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[1];
+        }
+    }
+    // FUSED: float4 c (columns 4c..4c+3) of the residual row, by thread c < 144: x_mid + the down slabs
+    float4 xr4 = make_float4(0.f, 0.f, 0.f, 0.f), xd4[FUSED ? Q2_HC : 1];
+    if (FUSED && tid < 144) {
+        const int64_t fi = ((int64_t)(b >> 5) * 72 + (tid >> 1)) * 64 + (b & 31) + 32 * (tid & 1);      // f32_idx(rb, 72, m, 4 tid)
+        xr4 = reinterpret_cast<const float4*>(a.xmidF)[fi];
+#pragma unroll
+        for (int s = 0; s < Q2_HC; ++s) xd4[s] = reinterpret_cast<const float4*>(a.dslabF)[(int64_t)s * a.slabF_stride4 + fi];
     }
     const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
     const int gbeg = sp * a.gs;                                   // groups of 4 keys
@@ -266,7 +282,22 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const int ngroups = (pos + 3) >> 2;                           // groups of 4 cached keys
     const int gend = min(ngroups, gend_fixed);
     static_assert(DEC_KC_QKV == 8, "fixed summation order below");
-    if (tid < 80) {
+    if (FUSED) {
+        if (tid < 192) {                     // waves 0..2: the residual row and its sum of squares (threads 144..191 add zeros)
+            float4 x = xr4;
+#pragma unroll
+            for (int s = 0; s < Q2_HC; ++s) x = f4add(x, xd4[s]);                // slab 0, then 1, ...
+            const float ss = wave_sum(tid < 144 ? f4ssq(x) : 0.f);
+            if (lane == 0) ssq_part[wave] = ss;
+            if (g == 0 && sp == 0 && tid < 144) reinterpret_cast<float4*>(a.xnewR + (int64_t)b * 576)[tid] = x;
+        }
+        if (tid < 80) {
+            float4 x = sl4[0];
+#pragma unroll
+            for (int s = 1; s < NPQ; ++s) x = f4add(x, sl4[s]);
+            *reinterpret_cast<float4*>(xs + 4 * tid) = x;          // scaled by the RMS statistic after the barrier
+        }
+    } else if (tid < 80) {
         float4 x = sl4[0];
 #pragma unroll
         for (int s = 1; s < DEC_KC_QKV; ++s) x = f4add(x, sl4[s]);           // slab 0, then 1, ... (the order of every build)
@@ -275,9 +306,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
         *reinterpret_cast<float4*>(xs + 4 * tid) = make_float4(x.x * rscale, x.y * rscale, x.z * rscale, x.w * rscale);
     }
     __syncthreads();
+    kstamp(1, 2, dbg);
+    const float rs2 = FUSED ? 1.0f / sqrtf(((ssq_part[0] + ssq_part[1]) + ssq_part[2]) / 576.0f + a.eps) : 1.0f;
     if (tid < 128) {
         const int base = hsel < 3 ? hsel * 64 : 192;
-        const float x1 = xs[base + i], x2 = xs[base + i + 32];
+        const float x1 = xs[base + i] * rs2, x2 = xs[base + i + 32] * rs2;
         const float o1 = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sn));
         const float o2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sn));
         if (hsel < 3) {
@@ -288,7 +321,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             if (sp == 0) { kpage[(int64_t)pos * 64 + i] = o1; kpage[(int64_t)pos * 64 + i + 32] = o2; }
         }
     } else if (tid < 192) {
-        const float x1 = xs[256 + tid - 128];
+        const float x1 = xs[256 + tid - 128] * rs2;
         vnew[tid - 128] = x1;
         if (sp == 0) vpage[(int64_t)pos * 64 + (tid - 128)] = x1;
     }
@@ -747,6 +780,86 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
 }
 
 // ----------------------------------------------------------------------------------------------------
+// K5+K1  the down projection of layer l and the q/k/v projection of layer l+1 in ONE launch (no kernel boundary between them).
+//     qkv_{l+1} = W' x_new with x_new = x_mid + Wd h is linear in (x_mid, h):  W' x_mid + (W' Wd) h.  The product Q = W' Wd
+//     (960 x 1536) is formed once at load time in fp64 and rounded to fp32 (engine.cpp), and stored behind W' in one P-layout
+//     matrix Wq2 [30 n-tiles][72 + 192 k-tiles].  The residual stream itself still goes through Wd (the "side" tiles), so the
+//     composed weights only ever feed the next RMS-scaled projection, never the residual.
+//     Workgroup types (grid.x):   [0, 60)              x part: n-tile b % 30, k-chunk b / 30 (2 chunks of 36 k-tiles of x_mid)
+//                                 [60, 60 + 48 Q2_HC)  h part: k-chunk hc of h (192 / Q2_HC k-tiles);
+//                                                      n-tile < 30: Q rows -> pq slab 2 + hc;  n-tile >= 30: Wd rows -> down slab hc
+//     Consumer: dec_attn_kernel<FUSED> sums the Q2_NPQ pq slabs and forms x_new = x_mid + sum of the Q2_HC down slabs.
+// ----------------------------------------------------------------------------------------------------
+template <bool BLK>
+__global__ __launch_bounds__(Q2_WAVES * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wq2,
+                                                                  const float* __restrict__ Wd) {
+    __shared__ __attribute__((aligned(16))) float red[Q2_WAVES * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, rb = blockIdx.y;
+    MELLOW_BLK_EXIT(rb)
+    const bool dbg = tid == 0 && b == 60 && rb == 0;          // an h-part workgroup (the longest kind)
+    kstamp(7, 0, dbg);
+    constexpr int XT = 36 / Q2_WAVES, HT = (192 / Q2_HC) / Q2_WAVES;      // k-tiles per wave
+    static_assert(XT * Q2_WAVES == 36 && HT * Q2_WAVES * Q2_HC == 192, "waves must divide the k-chunks");
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int nt, slab;
+    bool side = false;
+    if (b < 60) {              // x part (workgroup-uniform branch; each side keeps its loads straight-line)
+        nt = b % 30; slab = b / 30;
+        const int k8_0 = slab * 36 + wave * XT;
+        const int64_t wslot = ((int64_t)nt * Q2_K8 + k8_0) * 64 + lane;
+        const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        float4 w[XT], x[XT];
+#pragma unroll
+        for (int i = 0; i < XT; ++i) { w[i] = ldg_nt(reinterpret_cast<const float4*>(Wq2) + wslot + i * 64); x[i] = xb[i * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < XT; ++i) acc = mfma4(acc, w[i], x[i]);
+    } else {                   // h part
+        const int idx = b - 60, hc = idx / 48;
+        nt = idx % 48;
+        side = nt >= 30;
+        slab = side ? hc : 2 + hc;
+        const int k8_0 = hc * (192 / Q2_HC) + wave * HT;
+        const float4* wp = side ? reinterpret_cast<const float4*>(Wd) + ((int64_t)(nt - 30) * 192 + k8_0) * 64 + lane
+                                : reinterpret_cast<const float4*>(Wq2) + ((int64_t)nt * Q2_K8 + 72 + k8_0) * 64 + lane;
+        const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
+        float4 w[HT], h4[HT];
+#pragma unroll
+        for (int i = 0; i < HT; ++i) { w[i] = ldg_nt(wp + i * 64); h4[i] = hp[i * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+        kstamp(7, 1, dbg);
+#pragma unroll
+        for (int i = 0; i < HT; ++i) acc = mfma4(acc, w[i], h4[i]);
+        kstamp(7, 2, dbg && acc[0] == acc[0]);
+        if (side) nt -= 30;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    kstamp(7, 3, dbg);
+    if (tid < 256) {
+        const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = 4 * gq + j;
+            float sacc = red[q * 64 + mm + 32 * hh];
+#pragma unroll
+            for (int wv = 1; wv < Q2_WAVES; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];      // fixed order
+            v[j] = sacc;
+        }
+        const int n = nt * 32 + 8 * gq + 4 * hh;
+        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (side) reinterpret_cast<float4*>(a.dslabF)[(int64_t)slab * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
+        else *reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n) = o;
+    }
+    kstamp(7, 4, dbg);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // row-parallel helpers (one workgroup per batch row)
 // ----------------------------------------------------------------------------------------------------
 // final RMSNorm: xn = w * ((x_mid + sum down slabs) * rsqrt(mean^2 + eps)) -> F32-layout operand of the lm_head
@@ -754,6 +867,7 @@ template <int KCD, bool BLK>
 __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, const float* __restrict__ norm_w) {
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (BLK && b == 0 && tid < 32) a.blk_snap[tid] = a.blk_live[tid];      // for this step's arg-max (kernels.h)
     MELLOW_BLK_EXIT(b >> 5)
     const int xi = tid < 144 ? tid : 0;
     const int64_t fi = f32_idx(b >> 5, 72, b & 31, xi * 4);
@@ -789,7 +903,7 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
     // a slot whose whole block has stopped (or that is empty after a repack) computes nothing any more, but still takes part
     // in the step's arrival count
     const int row = lp.row_of_slot ? lp.row_of_slot[b] : b;         // the example in this slot
-    const bool dead = (lp.blk_live && lp.blk_live[b >> 5] == 0) || row < 0;      // workgroup-uniform; written by an EARLIER launch
+    const bool dead = (lp.blk_snap && lp.blk_snap[b >> 5] == 0) || row < 0;      // workgroup-uniform; written by an EARLIER launch
     float best = -INFINITY;
     int idx = 0x7fffffff;
     if (!dead) {
@@ -956,8 +1070,38 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
     else MELLOW_QKV(DEC_KC_DOWN, false);
 #undef MELLOW_QKV
 }
-void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s) {
-    MELLOW_LAUNCH_BLK(dec_attn_kernel, dim3(3, a.rows, DEC_TS), dim3(DA_WAVES * 64), a, k_cache, v_cache);
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
+    const dim3 grid(3, a.rows, DEC_TS), block(DA_WAVES * 64);
+    if (a.blk_live && fused) hipLaunchKernelGGL((dec_attn_kernel<true, true>), grid, block, 0, s, a, k_cache, v_cache);
+    else if (a.blk_live) hipLaunchKernelGGL((dec_attn_kernel<true, false>), grid, block, 0, s, a, k_cache, v_cache);
+    else if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true>), grid, block, 0, s, a, k_cache, v_cache);
+    else hipLaunchKernelGGL((dec_attn_kernel<false, false>), grid, block, 0, s, a, k_cache, v_cache);
+}
+void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
+    const dim3 grid(Q2_BLOCKS, a.RB), block(Q2_WAVES * 64);
+    if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true>), grid, block, 0, s, a, Wq2, Wd);
+    else hipLaunchKernelGGL((dec_qkv2_kernel<false>), grid, block, 0, s, a, Wq2, Wd);
+}
+// C[M][N] (fp32) = A[M][K] . B[K][N] with fp64 products and accumulation, rounded once: the load-time composition of two
+// weight matrices (W_qkv' . W_down) for dec_qkv2_kernel.  16 x 16 outputs per workgroup, operands staged through LDS.
+__global__ __launch_bounds__(256) void compose_f64_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                          int M, int N, int K) {
+    __shared__ double as[16][17], bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        as[ty][tx] = (m < M && k0 + tx < K) ? (double)A[(int64_t)m * K + k0 + tx] : 0.0;
+        bs[ty][tx] = (k0 + ty < K && n < N) ? (double)B[(int64_t)(k0 + ty) * N + n] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc += as[ty][kk] * bs[kk][tx];
+        __syncthreads();
+    }
+    if (m < M && n < N) C[(int64_t)m * N + n] = (float)acc;
+}
+void launch_compose_f64(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(compose_f64_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, A, B, C, M, N, K);
 }
 int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {

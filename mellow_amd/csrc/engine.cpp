@@ -17,6 +17,7 @@
 #include <map>
 #include <unordered_map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mellow_hip.h"
@@ -98,6 +99,9 @@ struct LMLayerW {
     Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
     float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
     float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, tile = 8 gate rows + the 8 matching up rows
+    // decode, layers >= 1: [W'_l | W'_l Wd_{l-1}] (960 x (576 + 1536), P-layout, the product formed in fp64 at load time): the
+    // operand of dec_qkv2_kernel, which runs the down projection of layer l-1 and the q/k/v projection of layer l as one launch
+    float* qkv2 = nullptr;
     // fp8 mode: e4m3 copies of the four decode operands in the same slot order (one 4-byte word per float4 slot) and one
     // scale per packed weight row (launch_pack_dec_fp8)
     float *qkv8 = nullptr, *qkv_sc = nullptr, *o8 = nullptr, *o_sc = nullptr, *gu8 = nullptr, *gu_sc = nullptr, *dn8 = nullptr,
@@ -381,9 +385,31 @@ static void pack_weight_host(const float* w, int N, int K, int NP, int KP, float
                 }
 }
 
+// Rotary tables the way transformers' LlamaRotaryEmbedding builds them: inv_freq = 1 / theta^(2i/d) and the angle
+// position * inv_freq are fp32 (the powers below reproduce torch's fp32 inv_freq bit for bit, tests/test_abi_cpu.py); cos / sin
+// are evaluated in double and rounded once, i.e. correctly rounded fp32 -- torch's vectorised fp32 cos/sin are within 1 ulp of
+// that, and a binding that needs torch's own last bit loads "mellow.rope_cos/sin" instead (include/mellow_hip.h).
+static void rope_tables_host(float theta, int head_dim, int P, float* c, float* s) {
+    const int half = head_dim / 2;
+    for (int i = 0; i < half; ++i) {
+        const float x = (float)(2 * i) / (float)head_dim;
+        const float inv = 1.0f / (float)pow((double)theta, (double)x);
+        for (int p = 0; p < P; ++p) {
+            const float a = inv * (float)p;
+            c[(size_t)p * half + i] = (float)cos((double)a);
+            s[(size_t)p * half + i] = (float)sin((double)a);
+        }
+    }
+}
+
 extern "C" {
 
 int mellow_abi_version(void) { return MELLOW_ABI_VERSION; }
+int mellow_host_rope_tables(float theta, int head_dim, int max_pos, float* cos_out, float* sin_out) {
+    if (!(theta > 0.f) || head_dim <= 0 || head_dim % 2 || max_pos <= 0 || !cos_out || !sin_out) return fail("bad rope table arguments");
+    rope_tables_host(theta, head_dim, max_pos, cos_out, sin_out);
+    return 0;
+}
 const char* mellow_last_error(void) { return g_err.c_str(); }
 int mellow_device_count(void) {
     int n = 0;
@@ -591,7 +617,9 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(expect_shape(get(e, kr), kr, {kNfreq, 1, kNfft}));
         CHK(expect_shape(get(e, ki), ki, {kNfreq, 1, kNfft}));
         CHK(make_packed(e, get(e, kr)->f(), get(e, ki)->f(), kNfreq, kNfft, &e->dft));
-        static const bool no_fft = getenv("MELLOW_STFT_FFT") && getenv("MELLOW_STFT_FFT")[0] == '0';
+        // MELLOW_STFT_FFT=0: the DFT GEMM on the split kernel; MELLOW_X3_STFT=0: the whole front-end on the exact fp32 kernel
+        static const bool no_fft = (getenv("MELLOW_STFT_FFT") && getenv("MELLOW_STFT_FFT")[0] == '0') ||
+                                   (getenv("MELLOW_X3_STFT") && getenv("MELLOW_X3_STFT")[0] == '0');
         if (e->f32x3_terms && !no_fft && kNfft == 1024) {
             // the reference builds these weights as window[n] * cos / -sin(2 pi k n / N) (torchlibrosa STFT, frozen parameters);
             // a checkpoint that holds anything else keeps the GEMM.  Row k = 0 of the real part IS the window.
@@ -747,6 +775,16 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         e->decode_only_weight = false;
         if (e->fp8_decode) CHK(make_dec_fp8(e, e->lm_head.p, e->lm_head.NP / 32, (e->lm_head.KP / 8) * 64, 32, &e->head8, &e->head_sc));
     }
+    // scratch for the load-time weight composition of dec_qkv2_kernel (fp32 decode weights only)
+    float *cmpF = nullptr, *cmpD = nullptr, *cmpQ = nullptr, *cmpCat = nullptr;
+    static const bool no_fuse = getenv("MELLOW_DECODE_FUSE") && getenv("MELLOW_DECODE_FUSE")[0] == '0';   // keep the 5-launch layer
+    const bool fuse = !e->fp8_decode && !no_fuse && H == 576 && I == 1536;
+    if (fuse) {
+        HIPCHK(hipMalloc(&cmpF, (size_t)960 * 576 * 4));
+        HIPCHK(hipMalloc(&cmpD, (size_t)576 * 1536 * 4));
+        HIPCHK(hipMalloc(&cmpQ, (size_t)960 * 1536 * 4));
+        HIPCHK(hipMalloc(&cmpCat, (size_t)960 * 2112 * 4));
+    }
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const std::string p = L + "model.layers." + std::to_string(l) + ".";
         LMLayerW w{};
@@ -776,6 +814,20 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
             e->decode_only_weight = true;
             CHK(make_packed(e, f.data(), nullptr, 960, H, &w.qkv_f));
             e->decode_only_weight = false;
+            if (fuse && l > 0) {
+                // Q = W'_l . Wd_{l-1} in fp64, rounded once; then [W'_l | Q] re-tiled into P-layout
+                const std::string kd = L + "model.layers." + std::to_string(l - 1) + ".mlp.down_proj.weight";
+                CHK(expect_shape(get(e, kd), kd, {H, I}));
+                HIPCHK(hipMemcpyAsync(cmpF, f.data(), (size_t)960 * 576 * 4, hipMemcpyHostToDevice, e->stream));
+                HIPCHK(hipMemcpyAsync(cmpD, get(e, kd)->f(), (size_t)576 * 1536 * 4, hipMemcpyHostToDevice, e->stream));
+                launch_compose_f64(cmpF, cmpD, cmpQ, 960, 1536, 576, e->stream);
+                HIPCHK(hipMemcpy2DAsync(cmpCat, (size_t)2112 * 4, cmpF, (size_t)576 * 4, (size_t)576 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
+                HIPCHK(hipMemcpy2DAsync(cmpCat + 576, (size_t)2112 * 4, cmpQ, (size_t)1536 * 4, (size_t)1536 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
+                CHK(dev_alloc(e, &w.qkv2, (size_t)1024 * 2112));
+                launch_pack_weight(cmpCat, 960, 2112, 2112, w.qkv2, 1024, 2112, e->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(e->stream));
+            }
             std::vector<float> gf((size_t)I * H), uf((size_t)I * H);
             for (int n = 0; n < I; ++n)
                 for (int kk = 0; kk < H; ++kk) {
@@ -802,6 +854,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         }
         e->layers.push_back(w);
     }
+    if (cmpF) { HIPCHK(hipFree(cmpF)); HIPCHK(hipFree(cmpD)); HIPCHK(hipFree(cmpQ)); HIPCHK(hipFree(cmpCat)); }
     CHK(up_vec(e, L + "model.norm.weight", H, &e->final_norm));
     // ---- RoPE tables [max_pos][32]: supplied by the host wrapper (computed the HF way with torch) or built here ----
     {
@@ -812,14 +865,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
             memcpy(c.data(), tc->f(), c.size() * 4);
             memcpy(s.data(), ts->f(), s.size() * 4);
         } else {
-            for (int i = 0; i < 32; ++i) {
-                const float inv = 1.0f / powf(e->cfg.rope_theta, (float)(2 * i) / 64.0f);
-                for (int p = 0; p < P; ++p) {
-                    const float a = inv * (float)p;
-                    c[(size_t)p * 32 + i] = cosf(a);
-                    s[(size_t)p * 32 + i] = sinf(a);
-                }
-            }
+            rope_tables_host(e->cfg.rope_theta, 64, P, c.data(), s.data());
         }
         CHK(upload(e, &e->rope_cos, c.data(), c.size()));
         CHK(upload(e, &e->rope_sin, s.data(), s.size()));
@@ -838,7 +884,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     e->d_seen = e->d_tokens + 2048;
     e->d_row_of_slot = e->d_tokens + 3072;
     e->d_ncompact = e->d_tokens + 1029;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped | hipHostMallocCoherent));
     *e->h_progress = 0;
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_progress), e->h_progress, 0));
     e->host.clear();
@@ -1116,7 +1162,6 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
             HIPCHK(hipMemsetAsync(e->dec.p, 0, off * sizeof(float), e->stream));
             if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
             if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
-        if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
         }
         float* p = e->dec.p;
         DecArgs& a = e->da;
@@ -1169,7 +1214,7 @@ static LoopArgs loop_args(mellow_engine* e) {
     lp.out_tokens = reinterpret_cast<int32_t*>(e->out_tok.p);
     lp.params = e->d_params; lp.seen_stop = e->d_seen; lp.n_seen = e->d_nseen; lp.arrive = e->d_arrive; lp.ticket = e->d_ticket;
     lp.host_progress = e->d_progress; lp.T0 = e->cfg.prefix_len;
-    if (e->da.blk_live) { lp.blk_left = e->d_blk_left; lp.blk_live = e->d_blk_live; }
+    if (e->da.blk_live) { lp.blk_left = e->d_blk_left; lp.blk_live = e->d_blk_live; lp.blk_snap = e->d_blk_live + 32; }
     if (e->da.row_of_slot) { lp.row_of_slot = e->d_row_of_slot; lp.n_compactions = e->d_ncompact; }
     return lp;
 }
@@ -1266,26 +1311,48 @@ static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int 
     const int Bp = e->da.rows;
     // developer knobs (wrong tokens, timing only): every layer on layer 0's weights / KV pages -- is a decode kernel's time the
     // cold fetch of its weights (538 MB per step cycle through the 256 MB Infinity Cache) or of its KV pages?
+    // Compiled in only with -DMELLOW_DEVPROBE (tools/ab_build.sh): the release library has no switch that changes its answers.
+#ifdef MELLOW_DEVPROBE
     static const bool same_w = getenv("MELLOW_DEV_SAME_WEIGHTS") != nullptr, same_kv = getenv("MELLOW_DEV_SAME_KV") != nullptr;
+    // MELLOW_DEV_SKIP: bit mask of the per-layer launches left out (1 qkv, 2 attention, 4 o_proj, 8 gate/up, 16 down): what a
+    // fusion that removes that launch could gain at most
+    static const int skip = getenv("MELLOW_DEV_SKIP") ? atoi(getenv("MELLOW_DEV_SKIP")) : 0;
+#else
+    constexpr bool same_w = false, same_kv = false;
+    constexpr int skip = 0;
+#endif
     for (int l = l_begin; l < l_end; ++l) {
         const LMLayerW& w = e->layers[same_w ? 0 : l];
         float* kc = e->kcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         float* vc = e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
+        // fused_in: this layer's q/k/v slabs (and the down slabs of x_new) were written by the previous layer's dec_qkv2 launch
+        const bool fused_in = l > l_begin && w.qkv2 != nullptr && !same_w;
         DecArgs a = e->da;
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
         a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
+        if (!(skip & 1) && !fused_in)
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 960.0, 576.0 * 960.0 * 4);
           if (w.qkv8) launch_dec_qkv(a, w.qkv8, w.qkv_f.KP / 8, kcd, s, w.qkv_sc);
           else launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
+        if (!(skip & 2))
         { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
-          launch_dec_attn(e->da, kc, vc, s); }
+          launch_dec_attn(e->da, kc, vc, fused_in, s); }
+        if (!(skip & 4))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
           if (w.o8) launch_dec_oproj(e->da, w.o8, s, w.o_sc);
           else launch_dec_oproj(e->da, w.o16, s); }
+        if (!(skip & 8))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
           if (w.gu8) launch_dec_gateup(e->da, w.gu8, s, w.gu_sc);
           else launch_dec_gateup(e->da, w.gu16, s); }
+        const float* next_qkv2 = (l + 1 < l_end && !same_w) ? e->layers[l + 1].qkv2 : nullptr;
+        if (next_qkv2) {
+            // the down projection of this layer and the q/k/v projection of the next one as one launch (decode.hip, dec_qkv2_kernel)
+            if (!(skip & 16))
+            { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * 4);
+              launch_dec_qkv2(e->da, next_qkv2, w.down.p, s); }
+        } else if (!(skip & 16))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
           if (w.dn8) launch_dec_down(e->da, w.dn8, w.down.KP / 8, s, w.dn_sc);
           else launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
@@ -1513,7 +1580,14 @@ static int wait_ticket(mellow_engine* e, unsigned want, unsigned* nseen) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
                 return fail("timed out waiting for decode ticket %u", want);
         }
+        // spin politely: a pause per poll, and after ~50 us of spinning yield the core between polls (EnginePool runs one
+        // such loop per context thread)
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("yield");
+#endif
+        if (spins > 4096) std::this_thread::yield();
     }
 }
 
@@ -1548,12 +1622,17 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     // row never reached are -1 in the token record.
     e->da.logits = nullptr;             // generation needs the arg-max candidates only: no 6 MB logits store per step
     e->da.blk_live = (!ignore_stop && e->da.RB > 1) ? e->d_blk_live : nullptr;
+    e->da.blk_snap = e->d_blk_live + 32;
+#ifdef MELLOW_DEVPROBE
     static const bool dev_dead = getenv("MELLOW_DEV_DEAD_BLOCKS") != nullptr;    // developer probe: launch-chain floor of a step
+#else
+    constexpr bool dev_dead = false;
+#endif
     static const bool no_migrate = getenv("MELLOW_NO_ROW_MIGRATION") != nullptr;   // developer A/B: block exit without repacking
     e->da.row_of_slot = nullptr;
     if (dev_dead) {
         e->da.blk_live = e->d_blk_live;
-        HIPCHK(hipMemsetAsync(e->d_blk_left, 0, 64 * sizeof(int32_t), s));
+        HIPCHK(hipMemsetAsync(e->d_blk_left, 0, 96 * sizeof(int32_t), s));
     } else if (e->da.blk_live) {
         if (!no_migrate && B <= 1024) {
             std::vector<int32_t> ident(1024);

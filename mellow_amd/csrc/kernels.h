@@ -97,6 +97,18 @@ constexpr int DEC_KC_DOWN = MELLOW_DEC_KC_DOWN;   // down: 192 k-tiles = 8 chunk
 #define MELLOW_DEC_TS 2
 #endif
 constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention, merged by the o_proj prologue
+// dec_qkv2_kernel (down projection of layer l + q/k/v of layer l+1 in one launch): k-chunks of the h part, waves, derived counts
+#ifndef MELLOW_Q2_HC
+#define MELLOW_Q2_HC 4
+#endif
+#ifndef MELLOW_Q2_WAVES
+#define MELLOW_Q2_WAVES 12
+#endif
+constexpr int Q2_HC = MELLOW_Q2_HC, Q2_WAVES = MELLOW_Q2_WAVES;
+constexpr int Q2_NPQ = 2 + Q2_HC;             // qkv slabs the fused kernel emits: 2 chunks of x_mid + Q2_HC chunks of h
+constexpr int Q2_K8 = 72 + 192;               // k-tiles of a Wq2 row: [W' (576 columns) | W' Wd (1536 columns)]
+constexpr int Q2_BLOCKS = 60 + 48 * Q2_HC;    // workgroups per row block
+static_assert(Q2_NPQ <= DEC_KC_QKV && Q2_HC <= DEC_KC_DOWN, "the fused kernel reuses the slab buffers of the split-K kernels");
 struct DecArgs {
     int rows = 0, RB = 0;          // padded batch rows (multiple of 32), row blocks
     int Tmax = 0;
@@ -124,6 +136,9 @@ struct DecArgs {
     // per-row-block early exit (reference stop rule, batches of more than one 32-row block): blk_live[rb] == 0 once every
     // row of block rb has produced the stop id -- its workgroups return at once.  Null = never skip (one block / fixed length).
     const int32_t* blk_live = nullptr;
+    // copy of blk_live taken by the final-norm launch of the step: what the step's arg-max tests, so that the rows of a block
+    // whose last row stops in THIS arg-max launch all still record this step's token, whatever order its workgroups run in
+    int32_t* blk_snap = nullptr;
     // row migration (same mode): row_of_slot[s] = the example whose state lives in batch slot s, or -1 for an empty slot.  The
     // slot addresses everything a step computes (activations, slabs); the example addresses what persists (its KV pages, its
     // token record, its stop flag).  dec_compact_kernel repacks the rows that are still running into the lowest slots
@@ -136,7 +151,13 @@ struct DecArgs {
 // layout (launch_pack_dec_fp8: one 4-byte word per float4 slot) and wscale holds one factor per packed weight row
 void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, hipStream_t s, const float* wscale = nullptr);
 void launch_pack_dec_fp8(const float* Wp, int tiles, int slots_per_tile, int rows_per_tile, void* out, float* scale, hipStream_t s);
-void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, hipStream_t s);
+// fused = the projected values come from launch_dec_qkv2 (Q2_NPQ slabs; the attention also forms x_new from the down slabs)
+void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s);
+// down projection of a layer + q/k/v projection of the next one: Wq2 = P-layout [30][Q2_K8] of [W'_{l+1} | W'_{l+1} Wd_l],
+// Wd = this layer's down weight in P-layout (K8p = 192)
+void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
+// C[M][N] = A[M][K] . B[K][N], fp64 accumulate, rounded once to fp32 (row-major device buffers)
+void launch_compose_f64(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
 int dec_attn_chunk_groups();   // 4-key groups one attention workgroup covers per pass
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s, const float* wscale = nullptr);
@@ -156,6 +177,7 @@ struct LoopArgs {
     int32_t* ticket = nullptr;           // arg-max launches since the start of the call
     int32_t* blk_left = nullptr;         // [row blocks] rows of the block that have not produced the stop id yet
     int32_t* blk_live = nullptr;         // [row blocks] cleared by the row that brings blk_left to 0 (DecArgs::blk_live)
+    const int32_t* blk_snap = nullptr;   // [row blocks] blk_live as it was before this step's arg-max (DecArgs::blk_snap)
     int32_t* row_of_slot = nullptr;      // [rows] example of each batch slot (DecArgs::row_of_slot); null: slot == example
     int32_t* n_compactions = nullptr;    // repacks done during the call (diagnostic)
     unsigned long long* host_progress = nullptr;   // mapped host memory

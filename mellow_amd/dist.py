@@ -19,32 +19,26 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
-def gather_tokens(tokens: np.ndarray, lengths: np.ndarray, n_total: int, max_len: int, device=None):
+def gather_tokens(tokens: np.ndarray, lengths: np.ndarray, n_total: int, max_len: int, device=None, per_rank: int = 0):
     """All-gather variable-size shards: tokens int32 [n_local, steps_local<=max_len], lengths int32 [n_local].
-    Returns (tokens [n_total, max_len] padded with -1, lengths [n_total]) on every rank."""
+    Returns (tokens [n_total, max_len] padded with -1, lengths [n_total]) on every rank.
+    ONE code path for every backend: `dist.all_gather` of equally sized int32 blocks into a list of tensors on `device`
+    (cuda under "nccl" = RCCL over xGMI, cpu under gloo), so the line the 8-GPU run executes is the line the tests executed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         out = np.full((n_total, max_len), -1, dtype=np.int32)
         out[: tokens.shape[0], : tokens.shape[1]] = tokens
         return out, np.asarray(lengths, dtype=np.int32)
     world = dist.get_world_size()
-    per = (n_total + world - 1) // world
+    per = per_rank or (n_total + world - 1) // world
     dev = device if device is not None else torch.device("cpu")
     buf = torch.full((per, max_len + 1), -1, dtype=torch.int32, device=dev)
     if tokens.shape[0]:
         buf[: tokens.shape[0], : tokens.shape[1]] = torch.as_tensor(tokens, dtype=torch.int32, device=dev)
         buf[: tokens.shape[0], max_len] = torch.as_tensor(lengths, dtype=torch.int32, device=dev)
-    out = torch.empty((world * per, max_len + 1), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out, buf) if hasattr(dist, "all_gather_into_tensor") and dev.type != "cpu" else \
-        _all_gather_list(out, buf, world, per)
-    out = out.cpu().numpy()[:n_total]
-    return out[:, :max_len].copy(), out[:, max_len].copy()
-
-
-def _all_gather_list(out: torch.Tensor, buf: torch.Tensor, world: int, per: int):
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
-    for r, p in enumerate(parts):
-        out[r * per:(r + 1) * per] = p
+    out = torch.cat(parts, 0).cpu().numpy()[:n_total]
+    return out[:, :max_len].copy(), out[:, max_len].copy()
 
 
 def generate_sharded(generate_fn, audio1, audio2, input_ids, max_len: int, device=None, **kw):

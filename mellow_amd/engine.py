@@ -18,7 +18,7 @@ from .spec import LMConfig
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmellow_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _F32, _I32, _I64 = 0, 1, 2
 
@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
         "mellow_host_pack_weight": (ci, [P(cf), ci, ci, ci, P(cf), i64]),
+        "mellow_host_rope_tables": (ci, [cf, ci, ci, P(cf), P(cf)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -109,7 +110,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft",
-    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight",
+    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
 )
 
 

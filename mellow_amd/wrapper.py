@@ -64,8 +64,9 @@ class MellowWrapper:
         """Reference signature `MellowWrapper(config, model, device, use_cuda=True)` (wrapper.py:35) plus keyword-only
         extensions: `checkpoint` (a local .ckpt instead of the hub download), `state_dict` (already loaded), `tokenizer`
         (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; the decode
-        attention supports 2048 keys), `data_parallel` (None: shard `generate` over the ranks of an initialised
-        torch.distributed group, one process per GPU; False: never), `precision` ("f32" | "f32x3" | "fp8")."""
+        attention supports 2048 keys), `data_parallel` (True or MELLOW_DATA_PARALLEL=1: shard `generate` over the ranks of an
+        initialised torch.distributed group, one process per GPU, every rank calling with the SAME examples -- checked; default
+        off: like the reference, every process answers its own examples), `precision` ("f32" | "f32x3" | "fp8")."""
         self.supported_versions = self.model_name.keys()
         if model not in self.supported_versions:
             raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
@@ -203,11 +204,29 @@ class MellowWrapper:
     def _dp(self):
         """(rank, world) of the data-parallel group `generate` shards over, (0, 1) when not distributed."""
         import torch.distributed as dist
-        if self._data_parallel is False or os.environ.get("MELLOW_DATA_PARALLEL") == "0":
-            return 0, 1
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # opt-in (the reference has no such behaviour: under torchrun every rank normally holds its OWN examples)
+        on = self._data_parallel is True or (self._data_parallel is None and os.environ.get("MELLOW_DATA_PARALLEL") == "1")
+        if on and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
+
+    def _check_same_examples(self, examples):
+        """Sharding is only meaningful when every rank was handed the same list: compare (count, digest) across ranks and
+        raise on every rank otherwise (a silent mismatch would return other ranks' texts, or hang in the gather)."""
+        import hashlib
+        import torch.distributed as dist
+        from . import dist as mdist
+        h = hashlib.sha256()
+        for ap1, ap2, tp in examples:
+            h.update(repr((str(ap1), str(ap2), str(tp))).encode())
+        mine = np.frombuffer(h.digest()[:8], dtype=np.int32).copy()
+        sig = np.concatenate([np.asarray([len(examples)], dtype=np.int32), mine])[None, :]          # [1, 3]
+        dev = self.model.tdev if dist.get_backend() == "nccl" else torch.device("cpu")
+        world = dist.get_world_size()
+        allsig, _ = mdist.gather_tokens(sig, np.zeros((1,), dtype=np.int32), world, 3, device=dev, per_rank=1)
+        if not (allsig == allsig[0]).all():
+            raise ValueError("data_parallel generate(): the ranks were given different `examples` "
+                             f"(counts {allsig[:, 0].tolist()}); call it with the same list on every rank, or turn sharding off")
 
     def _clamp_max_len(self, entry_length: int) -> int:
         limit = self.model.max_new_tokens_limit()
@@ -249,9 +268,9 @@ class MellowWrapper:
         stop_token: (str) token used to stop text generation
         audio_resample (bool) True for resampling audio. The model supports only 32 kHz
 
-        Under an initialised torch.distributed group (one process per GPU, every rank calling with the same examples)
-        the examples are sharded contiguously over the ranks, each rank ingests and runs only its shard, and every rank
-        returns the full list."""
+        With `data_parallel=True` (or MELLOW_DATA_PARALLEL=1) under an initialised torch.distributed group (one process per
+        GPU, every rank calling with the same examples) the examples are sharded contiguously over the ranks, each rank ingests
+        and runs only its shard, and every rank returns the full list."""
         audio_paths1, audio_paths2, text_prompts = [], [], []
         for example in examples:
             ap1, ap2, tp = example
@@ -265,6 +284,7 @@ class MellowWrapper:
         lo, hi = 0, n
         if world > 1:
             from .dist import shard_range
+            self._check_same_examples(examples)
             lo, hi = shard_range(n, rank, world)
         if hi > lo:
             audio1 = self.preprocess_audio(audio_paths1[lo:hi], resample=audio_resample)

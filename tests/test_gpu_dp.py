@@ -72,11 +72,22 @@ for i, (f, secs, sr) in enumerate(((440, 2.5, 44100), (1000, 10.0, 32000), (250,
     wav(p, f, secs, sr)
     paths.append(p)
 examples = [[paths[0], paths[1], "compare the two"], [paths[1], paths[2], "which is higher"], [paths[2], paths[0], "describe"]]
-m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok())
+m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=True)
 sharded = m.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)
+# sharding is opt-in and checked: ranks that hold DIFFERENT example lists are refused on every rank, nothing hangs
+try:
+    m.generate(examples=examples[: 2 + rank], max_len=6, top_p=0.8, temperature=1.0)
+    raise SystemExit("mismatching example lists were accepted")
+except ValueError as e:
+    assert "different `examples`" in str(e), e
+# default (like the reference): no sharding, every process answers its own list
+m0 = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok())
+own = m0.generate(examples=examples[rank: rank + 2], max_len=6, top_p=0.8, temperature=1.0)
+assert len(own) == 2
 m1 = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=False)
 alone = m1.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)
 assert len(sharded) == 3 and sharded == alone, (rank, sharded, alone)
+assert own == alone[rank: rank + 2], (rank, own, alone)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

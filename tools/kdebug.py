@@ -27,11 +27,12 @@ out = (C.c_uint64 * 64)()
 assert fn(eng.h, 0, out) == 0
 v = np.asarray(list(out), dtype=np.int64).reshape(8, 8)
 names = {0: "dec_qkv      [start, issued, mfma done, reduced(sync), pre-store]",
-         1: "dec_attn     [start, issued, sync1(data+stats), sync2(rope/lds), kv loop done, sync3, end]",
+         1: "dec_attn     [start, issued, sync1(slab sums in LDS), sync2(rope/lds), kv loop done, sync3, end]",
          2: "dec_oproj    [start, issued, merge+mfma done, sync, end]",
          3: "dec_gateup   [start, issued, mfma done, sync, end]",
          4: "dec_down     [start, issued, mfma done, sync, end]",
          5: "dec_lm_head  [start, issued, mfma done, sync, -]"}
+names[7] = "dec_qkv2     [start, issued, mfma done, sync, end]  (h-part workgroup)"
 for k, nm in names.items():
     row = v[k]
     base = row[0]
@@ -40,3 +41,13 @@ for k, nm in names.items():
 
 r = v[6]
 print("qkv startup probe (cycles): entry->kernarg", int(r[1]-r[0]), " kernarg->issued", int(r[2]-r[1]), " issued->first data", int(r[3]-r[2]))
+
+# absolute order of the last launches (same counter on every CU): gaps between one kernel's last stamp and the next one's first
+ev = []
+for k in (7, 1, 2, 3, 4, 5):
+    st = [int(x) for x in v[k][:7] if x]
+    if st:
+        ev.append((min(st), max(st), names[k].split()[0]))
+ev.sort()
+t0 = ev[0][0]
+print("timeline (cycles, workgroup 0 of each kernel):", [(n, a - t0, b - t0) for a, b, n in ev])
