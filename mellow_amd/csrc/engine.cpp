@@ -1263,7 +1263,8 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bo
         {
             // causal QK^T + PV: 4*64 flops per (query,key) pair per head
             ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
-            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, apb ? e->lm_o3.p : nullptr, B, T, Tmax, s);
+            static const bool attn_f32 = getenv("MELLOW_X3_ATTN") && getenv("MELLOW_X3_ATTN")[0] == '0';   // A/B: f32x3 mode on the fp32 kernel
+            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, apb ? e->lm_o3.p : nullptr, B, T, Tmax, e->f32x3_terms != 0 && !attn_f32, s);
         }
         {
             GemmArgs g = lin(e->lm_o.p, 576, M, w.o, x, 576, nullptr);

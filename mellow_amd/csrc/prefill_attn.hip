@@ -167,10 +167,200 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------
+// The same attention with both matrix products on the bf16 pipe, fp32-accurate (the f32x3 mode): K, Q, P and V are
+// each split EXACTLY into three bf16 pieces and the six largest partial products run on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (24 + 24 MFMAs of 32 cycles per 32 x 32 tile instead of 32 + 32 of 64).  Same workgroup shape and the same
+// transposed, register-resident softmax as above; what changes is the operand plumbing:
+//   * the loader wave splits K and V while it stages them and writes the pieces in MFMA FRAGMENT order (one 16-byte slot = the
+//     8 bf16 one lane feeds to one MFMA), so a compute wave's operand fetch is one conflict-free ds_read_b128 per piece:
+//       K image [d-step s 0..3][piece][lane = key + 32 * half]        8 bf16 = d 16 s + 8 half + (0..7)
+//       V image [key-step t 0..1][d-half][piece][lane = d + 32 * h]   8 bf16 = keys 16 t + (j&3) + 8 (j>>2) + 4 h, j = 0..7
+//     The key order inside a V slot is the order in which the score accumulators hold a query's 16 keys of a step, so the P
+//     registers (split in place) are the B operand as they are -- no cross-lane movement of P, no transposition of V by the
+//     compute waves.  The loader lane that owns (d-quad, t, h) loads exactly those 8 keys, so V is transposed in registers.
+//   * V slots are stored at lane ^ ((lane >> 3) & 3): a lane group of the 16-byte store then covers 8 distinct bank quads
+//     (the plain order would put its 8 lanes on 2), and the read groups of ds_read_b128 stay conflict-free.
+// ----------------------------------------------------------------------------------------------------------------------------
+constexpr int PAX_K_SLOTS = 4 * 3 * 64, PAX_V_SLOTS = 2 * 2 * 3 * 64;
+__device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
+#define PAX_MFMA(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
+// the six partial products of (a0 + a1 + a2)(b0 + b1 + b2) that are not below 2^-23 of the result, smallest first
+#define PAX_6(A0, A1, A2, B0, B1, B2, ACC) \
+    do { PAX_MFMA(A2, B0, ACC); PAX_MFMA(A1, B1, ACC); PAX_MFMA(A0, B2, ACC); PAX_MFMA(A1, B0, ACC); PAX_MFMA(A0, B1, ACC); PAX_MFMA(A0, B0, ACC); } while (0)
+
+__global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
+                                                                   const float* __restrict__ v_cache, float* __restrict__ o,
+                                                                   i32x4* __restrict__ o_apb, int T, int Tmax) {
+    __shared__ i32x4 Kp[2][PAX_K_SLOTS];
+    __shared__ i32x4 Vp[2][PAX_V_SLOTS];
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+    const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
+
+    if (wave == 3) {
+        // ---------------- loader wave: 8 + 8 float4 per lane per tile, split, 12 + 12 sixteen-byte LDS stores ----------------
+        f32x4 pk[8], pv[8];
+        const int klo = lane & 7, oct = lane >> 3;               // K: keys klo + 8 i (i = 0..3), the 8 dims 8 oct .. 8 oct + 7
+        const int q4 = lane & 15, t2 = (lane >> 4) & 1, hv = lane >> 5;     // V: dims 4 q4 .. + 3, key step t2, key half hv
+        auto fetch = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = kt * 32 + klo + 8 * i;
+                t = t < T ? t : T - 1;
+                pk[2 * i] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + oct * 8);
+                pk[2 * i + 1] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + oct * 8 + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int t = kt * 32 + 16 * t2 + (j & 3) + 8 * (j >> 2) + 4 * hv;
+                t = t < T ? t : T - 1;
+                pv[j] = *reinterpret_cast<const f32x4*>(vpage + (int64_t)t * 64 + q4 * 4);
+            }
+        };
+        auto stage = [&](int st) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v[8] = {pk[2 * i][0], pk[2 * i][1], pk[2 * i][2], pk[2 * i][3],
+                                    pk[2 * i + 1][0], pk[2 * i + 1][1], pk[2 * i + 1][2], pk[2 * i + 1][3]};
+                i32x4 p0, p1, p2;
+                split8(v, p0, p1, p2);
+                i32x4* dst = &Kp[st][((oct >> 1) * 3) * 64 + klo + 8 * i + 32 * (oct & 1)];
+                dst[0] = p0; dst[64] = p1; dst[128] = p2;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v[8] = {pv[0][e], pv[1][e], pv[2][e], pv[3][e], pv[4][e], pv[5][e], pv[6][e], pv[7][e]};
+                i32x4 p0, p1, p2;
+                split8(v, p0, p1, p2);
+                const int d = 4 * q4 + e;
+                i32x4* dst = &Vp[st][((t2 * 2 + (d >> 5)) * 3) * 64 + pax_sw((d & 31) + 32 * hv)];
+                dst[0] = p0; dst[64] = p1; dst[128] = p2;
+            }
+        };
+        fetch(0);
+        stage(0);
+        fetch(qt >= 1 ? 1 : 0);
+        __syncthreads();                                   // tile 0 visible
+        for (int kt = 0; kt <= qt; ++kt) {
+            stage((kt + 1) & 1);                           // tile kt+1 (or a harmless re-read past the end) -> other stage
+            fetch(kt + 2 <= qt ? kt + 2 : qt);
+            __syncthreads();                               // compute waves are done with stage kt & 1; stage (kt+1) & 1 is visible
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    const int hq = 3 * g + wave;
+    const int h = lane >> 5, ql = lane & 31;
+    const int q0 = qt * 32;
+    const int qi = q0 + ql;
+    const int qc = qi < T ? qi : T - 1;
+    // Q as B operand of the bf16 MFMA: step s, lane (query ql, half h) holds d = 16 s + 8 h + (0..7), pre-scaled by 1/8 (exact)
+    i32x4 qp[4][3];
+    {
+        const float* qrow = q + ((int64_t)b * T + qc) * 576 + hq * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 16 * s), c = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            const float v[8] = {a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f, c.x * 0.125f, c.y * 0.125f, c.z * 0.125f, c.w * 0.125f};
+            split8(v, qp[s][0], qp[s][1], qp[s][2]);
+        }
+    }
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int vl = pax_sw(lane);
+    __syncthreads();                                       // tile 0 staged by the loader
+
+    for (int kt = 0; kt <= qt; ++kt) {
+        const int k0 = kt * 32;
+        const i32x4* Kc = Kp[kt & 1] + lane;
+        const i32x4* Vc = Vp[kt & 1] + vl;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const i32x4 a0 = Kc[(s * 3 + 0) * 64], a1 = Kc[(s * 3 + 1) * 64], a2 = Kc[(s * 3 + 2) * 64];
+            PAX_6(a0, a1, a2, qp[s][0], qp[s][1], qp[s][2], S);
+        }
+        // lane: query ql, keys k0 + (r&3) + 8(r>>2) + 4h
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key > qi) S[r] = -INFINITY;          // causal mask (only bites on the diagonal tile)
+            tmax = fmaxf(tmax, S[r]);
+        }
+        tmax = half_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = pa_exp(m_run - m_new);
+        float rsum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = pa_exp(S[r] - m_new);
+            rsum += p[r];
+        }
+        rsum = half_sum(rsum);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+        // O^T[d][query] += sum_key V[key][d] P^T[key][query]: registers 8 t .. 8 t + 7 of P are the k-slots of key step t
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float v[8] = {p[8 * t], p[8 * t + 1], p[8 * t + 2], p[8 * t + 3], p[8 * t + 4], p[8 * t + 5], p[8 * t + 6], p[8 * t + 7]};
+            i32x4 b0, b1, b2;
+            split8(v, b0, b1, b2);
+            {
+                const i32x4 a0 = Vc[((t * 2 + 0) * 3 + 0) * 64], a1 = Vc[((t * 2 + 0) * 3 + 1) * 64], a2 = Vc[((t * 2 + 0) * 3 + 2) * 64];
+                PAX_6(a0, a1, a2, b0, b1, b2, O0);
+            }
+            {
+                const i32x4 a0 = Vc[((t * 2 + 1) * 3 + 0) * 64], a1 = Vc[((t * 2 + 1) * 3 + 1) * 64], a2 = Vc[((t * 2 + 1) * 3 + 2) * 64];
+                PAX_6(a0, a1, a2, b0, b1, b2, O1);
+            }
+        }
+        __syncthreads();                                   // done with stage kt & 1; the next tile is visible
+    }
+    if (qi < T) {
+        const float inv = 1.0f / l_run;
+        if (o_apb) {
+            const int64_t m = (int64_t)b * T + qi;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float X[4], Y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { X[j] = O0[8 * gp + j] * inv; Y[j] = O0[8 * gp + 4 + j] * inv; }
+                apb_store_quads(o_apb, m, hq * 8 + 2 * gp, 36, X, Y, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { X[j] = O1[8 * gp + j] * inv; Y[j] = O1[8 * gp + 4 + j] * inv; }
+                apb_store_quads(o_apb, m, hq * 8 + 4 + 2 * gp, 36, X, Y, h);
+            }
+        } else {
+            float* orow = o + ((int64_t)b * T + qi) * 576 + hq * 64;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d = 8 * gq + 4 * h;
+                *reinterpret_cast<float4*>(orow + d) =
+                    make_float4(O0[4 * gq] * inv, O0[4 * gq + 1] * inv, O0[4 * gq + 2] * inv, O0[4 * gq + 3] * inv);
+                *reinterpret_cast<float4*>(orow + 32 + d) =
+                    make_float4(O1[4 * gq] * inv, O1[4 * gq + 1] * inv, O1[4 * gq + 2] * inv, O1[4 * gq + 3] * inv);
+            }
+        }
+    }
+}
+
+// x3 = the bf16-split kernel (the engine's f32x3 mode), else exact fp32 MFMA
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, hipStream_t s) {
+                              int Tmax, bool x3, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
+    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
+    else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
 }
 
 }  // namespace mellow

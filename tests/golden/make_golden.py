@@ -306,11 +306,71 @@ def ragged_eos_cases(args, model, sd, lmp, t0, want):
         np.savez_compressed(os.path.join(args.out, "eos_mixed.npz"), stop_id=EOS_STOP, max_len=EOS_MAXLEN, **out)
 
 
+EX_SEED = 20250
+EX_STEPS = 300
+EX_PROMPT = "what is the primary sound event present in the clip? a) dog barking b) chirping birds c) car engine d) clapping"
+
+
+def example_ids(prompt, L=129):
+    """Tokenizer stand-in (the SmolLM2 files are not available offline): deterministic ids per word, right-padded with id 1 to
+    129 -- the same function the GPU test's stub tokenizer uses, so the prompt ids of both sides are equal by construction."""
+    ids = [17 + (sum(w.encode()) * 7919 + i * 104729) % 49000 for i, w in enumerate(prompt.split())][:L]
+    return ids + [1] * (L - len(ids))
+
+
+def example_case(args, model, t0):
+    """BASELINE configs[0] / reference example.py:20-31: the two fixture clips + the README prompt through the REFERENCE's own
+    `preprocess_audio` (wrapper.py:141-179: decode, resample to 32 kHz, flatten, tile 1.wav / crop 2.wav at a `random` offset),
+    `generate_prefix_inference` and the unmodified `_generate_batch` loop for max_len = 300.  Stored: the decoded int16 PCM of
+    both fixtures (data), the seed and the crop offset it produced, checks of the two preprocessed arrays, the prompt ids and
+    all 300 greedy tokens.  The resampler inside is this build's restatement (torchaudio absent: parity unpinned there)."""
+    import random
+    import wave
+    import yaml
+    from argparse import Namespace
+    from mellow.wrapper import MellowWrapper
+    pcm, srs = [], []
+    for name in ("1.wav", "2.wav"):
+        with wave.open(os.path.join(REF, "resource", name), "rb") as w:
+            assert w.getnchannels() == 1 and w.getsampwidth() == 2
+            srs.append(w.getframerate())
+            pcm.append(np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy())
+    w = MellowWrapper.__new__(MellowWrapper)
+    with open(os.path.join(REF, "mellow", "config", "v0.yaml")) as f:
+        w.args = Namespace(**yaml.safe_load(f))
+    w.use_cuda, w.device = False, "cpu"
+    random.seed(EX_SEED)
+    a1 = w.preprocess_audio([os.path.join(REF, "resource", "1.wav")], resample=True).squeeze(1)      # wrapper.py:277-278
+    a2 = w.preprocess_audio([os.path.join(REF, "resource", "2.wav")], resample=True).squeeze(1)
+    assert a1.shape == (1, 320000) and a2.shape == (1, 320000) and a1.dtype == torch.float32
+    # recover the crop offset the reference drew: replay the draw (2.wav resamples to 323,585 > 320,000 samples)
+    random.seed(EX_SEED)
+    n2 = int(np.ceil(320 * len(pcm[1]) / 441))
+    start = random.randrange(n2 - 320000)
+    ids = torch.tensor([example_ids(EX_PROMPT)], dtype=torch.int64)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": a1, "audio2": a2, "input": {"input_ids": ids}})
+        _, toks, logits_log = ref_generate_tokens(model, prefix, EX_STEPS, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    gaps = np.stack([(lambda t2: (t2[..., 0] - t2[..., 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in logits_log])
+    print(f"example: n1 {len(pcm[0])} -> {int(np.ceil(320 * len(pcm[0]) / 441))} (tiled), n2 {len(pcm[1])} -> {n2} (crop at {start}); "
+          f"{EX_STEPS} reference steps ({time.time() - t0:.1f}s); min top-2 gap {gaps.min():.4f}; tokens[:8] {toks[0, :8].tolist()}")
+    np.savez_compressed(
+        os.path.join(args.out, "example.npz"),
+        pcm1=pcm[0], pcm2=pcm[1], sr1=srs[0], sr2=srs[1], seed=EX_SEED, crop_start2=start, prompt=EX_PROMPT,
+        input_ids=ids.numpy(), steps=EX_STEPS, tokens=toks, top2_gap=gaps.astype(np.float32),
+        audio1_sub=a1[0, ::61].numpy(), audio2_sub=a2[0, ::61].numpy(),
+        audio1_sum=np.float64(a1.double().sum()), audio2_sum=np.float64(a2.double().sum()),
+        audio1_abs=np.float64(a1.double().abs().sum()), audio2_abs=np.float64(a2.double().abs().sum()),
+        prefix_sub=prefix[:, ::7, ::5].numpy(),
+    )
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64 "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64,example "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -411,6 +471,8 @@ def main():
         b64_tail_case(args, model, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
+    if want("example"):
+        example_case(args, model, t0)
     print(f"done ({time.time() - t0:.1f}s)")
 
 

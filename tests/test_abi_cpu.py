@@ -82,3 +82,26 @@ def test_pack_weight_fragment_order(lib):
     # mfma k-pairing: the 4 MFMAs of one float4 cover k0+j and k0+4+j -> all 8 k of the tile exactly once
     ks = sorted(k8 * 8 + 4 * h + j for k8 in range(1) for h in range(2) for j in range(4))
     assert ks == list(range(8))
+
+
+def test_rope_tables_helper_against_the_hf_computation(lib):
+    """`mellow_host_rope_tables` is what the engine uses when the binding does not load "mellow.rope_cos/sin"
+    (include/mellow_hip.h): same fp32 inv_freq / angle as transformers' LlamaRotaryEmbedding, cos / sin correctly rounded.
+    torch's vectorised fp32 cos / sin are allowed to differ from that by one unit in the last place, nothing more."""
+    P, D, theta = 2048, 64, 100000.0
+    c = np.empty((P, D // 2), dtype=np.float32)
+    s = np.empty((P, D // 2), dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    assert lib.mellow_host_rope_tables(theta, D, P, c.ctypes.data_as(fp), s.ctypes.data_as(fp)) == 0
+    hc, hs = E.hf_rope_tables(P, D, theta)
+    # the angle path is bit-identical: position 1 holds cos / sin of inv_freq itself, and exact identities hold at position 0
+    assert np.array_equal(c[0], np.ones(D // 2, dtype=np.float32)) and np.array_equal(s[0], np.zeros(D // 2, dtype=np.float32))
+    for got, ref in ((c, hc), (s, hs)):
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, ulp.max()
+        assert (ulp != 0).mean() < 0.10
+    # and against float64: the helper is the correctly rounded value
+    inv = (1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))).numpy()
+    ang = (np.arange(P, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float32).astype(np.float64)
+    assert np.array_equal(c, np.cos(ang).astype(np.float32)) and np.array_equal(s, np.sin(ang).astype(np.float32))
+    assert lib.mellow_host_rope_tables(theta, 63, P, c.ctypes.data_as(fp), s.ctypes.data_as(fp)) != 0

@@ -68,9 +68,11 @@ def wav(path, f, secs, sr):
 tmp = sys.argv[2]
 paths = []
 for i, (f, secs, sr) in enumerate(((440, 2.5, 44100), (1000, 10.0, 32000), (250, 4.0, 48000))):
-    p = os.path.join(tmp, f"r{rank}_{i}.wav")       # every rank writes the same content under its own name
-    wav(p, f, secs, sr)
+    p = os.path.join(tmp, f"clip_{i}.wav")          # one list of paths for every rank (rank 0 writes the files)
+    if rank == 0:
+        wav(p, f, secs, sr)
     paths.append(p)
+dist.barrier()
 examples = [[paths[0], paths[1], "compare the two"], [paths[1], paths[2], "which is higher"], [paths[2], paths[0], "describe"]]
 m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=True)
 sharded = m.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)

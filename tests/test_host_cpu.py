@@ -75,6 +75,32 @@ def test_reference_fixture_wavs_load():
     assert torch.equal(y[: r.shape[1]], r[0]) and torch.equal(y[r.shape[1]:], r[0, : 320000 - r.shape[1]])
 
 
+def test_host_ingest_against_the_reference_preprocess_audio_goldens():
+    """A0 on the committed fixture PCM (tests/golden/example.npz: resource/1.wav, 2.wav decoded to int16 -- data -- and the
+    arrays the REFERENCE's own preprocess_audio returned for them, generated in the build container): the tile case
+    403,604 @ 44.1 kHz -> 292,865 -> repeated to 320,000, and the crop case 445,940 -> 323,585 cut at the offset the reference
+    drew from `random` under the stored seed.  The resampling step inside both sides is this build's restatement of torchaudio's
+    (PARITY UNPINNED there: torchaudio is not installed); decode, flatten, tile, crop and the draw are pinned to the reference."""
+    import random
+    g = np.load(os.path.join(ROOT, "tests", "golden", "example.npz"))
+    assert int(g["sr1"]) == 44100 and g["pcm1"].shape == (403604,) and g["pcm2"].shape == (445940,) and g["pcm1"].dtype == np.int16
+    w1 = torch.from_numpy(g["pcm1"].astype(np.float32) / 32768.0)[None]
+    w2 = torch.from_numpy(g["pcm2"].astype(np.float32) / 32768.0)[None]
+    r1, r2 = audio.resample(w1, 44100, 32000)[0], audio.resample(w2, 44100, 32000)[0]
+    assert r1.shape == (292865,) and r2.shape == (323585,)
+    t1 = audio.fit_duration(r1, 320000)
+    assert torch.equal(t1[:292865], r1) and torch.equal(t1[292865:], r1[: 320000 - 292865])
+    random.seed(int(g["seed"]))
+    t2 = audio.fit_duration(r2, 320000)                               # draws random.randrange(323585 - 320000) like wrapper.py:164
+    start = int(g["crop_start2"])
+    assert torch.equal(t2, r2[start:start + 320000])
+    assert torch.equal(audio.fit_duration(r2, 320000, start_index=start), t2)
+    for t, name in ((t1, "audio1"), (t2, "audio2")):
+        assert float((t[::61] - torch.from_numpy(g[f"{name}_sub"])).abs().max()) <= 2e-6, name
+        assert abs(float(t.double().sum()) - float(g[f"{name}_sum"])) <= 0.5
+        assert abs(float(t.double().abs().sum()) - float(g[f"{name}_abs"])) <= 0.5
+
+
 def test_wrapper_error_conventions():
     from mellow_amd import MellowWrapper
     with pytest.raises(ValueError, match="not supported"):
