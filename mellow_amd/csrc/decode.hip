@@ -194,6 +194,10 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
 #endif
 constexpr int DA_WAVES = MELLOW_DA_WAVES;
 constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chunk covers 2 * DA_WAVES * DA_G * 4 = 448 keys
+#ifndef MELLOW_DA_G1
+#define MELLOW_DA_G1 5      // 5 of 7: 48.55 ms of decode per 63 steps; 2 / 3 / 4 / 7 (= everything up front): 49.35 / 49.15 / 49.0 / 49.75 (same box)
+#endif
+constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key groups requested before the prologue
 
 // FUSED: the producer was dec_qkv2_kernel (the previous layer's down projection and this layer's q/k/v in one launch): the
 // projected values arrive as Q2_NPQ slabs, and x_new = x_mid + sum of the Q2_HC down slabs is formed HERE (the 144 float4 of the
@@ -263,9 +267,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
     const int gbeg = sp * a.gs;                                   // groups of 4 keys
     const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + a.gs;
+    // The K/V stream of a workgroup (107 KB at 420 keys) is bound by what the memory side delivers per CU (~12 B/clk): a wave
+    // that issues all 14 page loads up front sits in the issue queue for ~4 us, and the prologue's barriers wait for the
+    // slowest wave.  So only the first DA_G1 key groups are requested before the prologue (enough bytes in flight to keep the
+    // stream busy while it runs: slab sums, RoPE, two barriers); the rest is requested after it, and the score loop consumes
+    // the groups in arrival order.
     float4 k4[DA_G], v4[DA_G];
-#pragma unroll
-    for (int u = 0; u < DA_G; ++u) {
+    auto load_group = [&](int u) {
         const int gi = gbeg + wave + u * DA_WAVES;
         const int tc = min(gi * 4 + sub, Tmax - 1);               // inside the page; validity is decided later
         if (MELLOW_DA_ABL & 1) {
@@ -275,7 +283,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
             k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
             v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < DA_G1; ++u) load_group(u);
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 1, dbg);
 
@@ -326,6 +336,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
         if (sp == 0) vpage[(int64_t)pos * 64 + (tid - 128)] = x1;
     }
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = DA_G1; u < DA_G; ++u) load_group(u);
+    __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 3, dbg);
 
     if (wave < 3) {                      // score of the new key (q . k_new, both in LDS), consumed after the last barrier
