@@ -224,11 +224,11 @@ def alt_modes(B: int, L: int, headline: str):
     return res
 
 
-def pipelined(n_ctx: int, B: int, L: int, n_batches: int):
-    """Supplementary: n_ctx engine contexts on one GPU, n_batches batches of B dealt round-robin (mellow_amd/serve.py)."""
+def pipelined(n_ctx: int, B: int, L: int, n_batches: int, precision: str = "f32x3"):
+    """Supplementary: n_ctx engine contexts (ONE weight copy) on one GPU, n_batches batches of B dealt round-robin (mellow_amd/serve.py)."""
     from mellow_amd import synth
     from mellow_amd.serve import EnginePool
-    pool = EnginePool(synth.make_state_dict(0), n_contexts=n_ctx, device=0)
+    pool = EnginePool(synth.make_state_dict(0), n_contexts=n_ctx, device=0, precision=precision)
     batches = []
     for i in range(n_batches):
         a1, a2, ids = synth.make_batch(B, first=i * B)
@@ -462,7 +462,7 @@ def main():
             _progress("leg: alt_modes")
             out["alt_modes"] = alt_modes(B, L, args.precision)
         if n_gpus == 1 and args.inflight > 1:
-            out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight))
+            out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight), args.precision)
         if n_gpus == 1 and args.precision != "fp8" and not args.no_b64 and B != 64:
             _progress("leg: north_star_b64")
             out["north_star_b64"] = north_star_b64(L, args.precision)

@@ -65,6 +65,11 @@ int         mellow_device_count(void);
  *      + model.to(cuda) (reference wrapper.py:59-88) ------------------------------------------------ */
 int  mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t** out);
 void mellow_engine_destroy(mellow_engine_t* e);
+/* A second execution context on the same device that SHARES a finalized engine's weights (no copy): its own HIP stream,
+ * workspaces, KV pages and captured graphs.  Calls on `parent` and on the fork may overlap from different host threads (a
+ * serving front-end pipelines independent batches this way: mellow_amd/serve.py); each handle is still serialised by its
+ * caller.  Destroy every fork before its parent.  The reference has no counterpart (one synchronous model object). */
+int  mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out);
 
 /* Hand one checkpoint tensor to the engine under its reference state_dict key, e.g.
  * "audio_encoder.base.htsat.layers.0.blocks.1.attn.qkv.weight".  `data` may be a host or a device

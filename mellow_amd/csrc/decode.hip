@@ -804,17 +804,18 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
 //                                                      n-tile < 30: Q rows -> pq slab 2 + hc;  n-tile >= 30: Wd rows -> down slab hc
 //     Consumer: dec_attn_kernel<FUSED> sums the Q2_NPQ pq slabs and forms x_new = x_mid + sum of the Q2_HC down slabs.
 // ----------------------------------------------------------------------------------------------------
-template <bool BLK>
-__global__ __launch_bounds__(Q2_WAVES * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wq2,
+// Q2W = waves per workgroup (chosen per launch: 4 for one row block, Q2W otherwise)
+template <bool BLK, int Q2W>
+__global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wq2,
                                                                   const float* __restrict__ Wd) {
-    __shared__ __attribute__((aligned(16))) float red[Q2_WAVES * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[Q2W * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, rb = blockIdx.y;
     MELLOW_BLK_EXIT(rb)
     const bool dbg = tid == 0 && b == 60 && rb == 0;          // an h-part workgroup (the longest kind)
     kstamp(7, 0, dbg);
-    constexpr int XT = 36 / Q2_WAVES, HT = (192 / Q2_HC) / Q2_WAVES;      // k-tiles per wave
-    static_assert(XT * Q2_WAVES == 36 && HT * Q2_WAVES * Q2_HC == 192, "waves must divide the k-chunks");
+    constexpr int XT = 36 / Q2W, HT = (192 / Q2_HC) / Q2W;      // k-tiles per wave
+    static_assert(XT * Q2W == 36 && HT * Q2W * Q2_HC == 192, "waves must divide the k-chunks");
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(Q2_WAVES * 64) void dec_qkv2_kernel(const DecArgs a
             const int q = 4 * gq + j;
             float sacc = red[q * 64 + mm + 32 * hh];
 #pragma unroll
-            for (int wv = 1; wv < Q2_WAVES; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];      // fixed order
+            for (int wv = 1; wv < Q2W; ++wv) sacc += red[(wv * 16 + q) * 64 + mm + 32 * hh];      // fixed order
             v[j] = sacc;
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
@@ -954,14 +955,17 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
                     if (lp.blk_left && atomicSub(lp.blk_left + (b >> 5), 1) == 1) lp.blk_live[b >> 5] = 0;   // from the NEXT step on
                 }
             }
-            // the last row of this launch publishes the step: ticket = arg-max launches so far, low word = rows stopped
-            __threadfence();
+            // the last row of this launch publishes the step: ticket = arg-max launches so far, low word = rows stopped.
+            // Ordering: this row's n_seen / blk_left atomics must have been performed before its arrival is counted -- a drained
+            // vmcnt is enough for device-scope atomics (no cache write-back: a __threadfence() here cost ~3 us per step).  The
+            // host reads only the progress word itself before the stream is synchronised, so its store needs no release.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (atomicAdd(lp.arrive, 1) == (int)gridDim.x - 1) {
                 *lp.arrive = 0;
                 const int t = *lp.ticket + 1;
                 *lp.ticket = t;
                 const int ns = atomicAdd(lp.n_seen, 0);
-                __hip_atomic_store(lp.host_progress, ((unsigned long long)(unsigned)t << 32) | (unsigned)ns, __ATOMIC_RELEASE,
+                __hip_atomic_store(lp.host_progress, ((unsigned long long)(unsigned)t << 32) | (unsigned)ns, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -1092,9 +1096,21 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
     else hipLaunchKernelGGL((dec_attn_kernel<false, false>), grid, block, 0, s, a, k_cache, v_cache);
 }
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
-    const dim3 grid(Q2_BLOCKS, a.RB), block(Q2_WAVES * 64);
-    if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true>), grid, block, 0, s, a, Wq2, Wd);
-    else hipLaunchKernelGGL((dec_qkv2_kernel<false>), grid, block, 0, s, a, Wq2, Wd);
+    // waves per workgroup: 4 x (9 | 12) k-tiles when there is one row block (a 4-way instead of a 12-way LDS reduction: 49.55 vs
+    // 49.98 ms of decode per 63 steps at B = 32), 12 x (3 | 4) otherwise (B = 64: 76.3 vs 77.2 ms); -DMELLOW_Q2_WAVES=n forces one
+    const dim3 grid(Q2_BLOCKS, a.RB);
+#ifdef MELLOW_Q2_WAVES_FORCED
+    const bool few = false;
+#else
+    const bool few = a.RB == 1;
+#endif
+    if (few) {
+        if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true, 4>), grid, dim3(256), 0, s, a, Wq2, Wd);
+        else hipLaunchKernelGGL((dec_qkv2_kernel<false, 4>), grid, dim3(256), 0, s, a, Wq2, Wd);
+    } else {
+        if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true, Q2_WAVES>), grid, dim3(Q2_WAVES * 64), 0, s, a, Wq2, Wd);
+        else hipLaunchKernelGGL((dec_qkv2_kernel<false, Q2_WAVES>), grid, dim3(Q2_WAVES * 64), 0, s, a, Wq2, Wd);
+    }
 }
 // C[M][N] (fp32) = A[M][K] . B[K][N] with fp64 products and accumulation, rounded once: the load-time composition of two
 // weight matrices (W_qkv' . W_down) for dec_qkv2_kernel.  16 x 16 outputs per workgroup, operands staged through LDS.

@@ -121,6 +121,7 @@ struct mellow_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool finalized = false;
+    bool owns_weights = true;                 // false for a context made by mellow_engine_fork: weight memory belongs to its parent
     std::map<std::string, HostTensor> host;   // until finalize
     std::vector<void*> allocs;                // everything hipMalloc'd for weights
     char* arena = nullptr;                    // one big allocation the weights are carved from
@@ -467,7 +468,8 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->step_exec) hipGraphExecDestroy(e->step_exec);
     if (e->step_exec8) hipGraphExecDestroy(e->step_exec8);
-    for (void* p : e->allocs) hipFree(p);
+    if (e->owns_weights)
+        for (void* p : e->allocs) hipFree(p);
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
                                   &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->lm_xn3, &e->lm_o3, &e->lm_h3, &e->kcache, &e->vcache, &e->dec,
@@ -604,6 +606,7 @@ static int pack_key(mellow_engine* e, const std::string& k, int N, int K, Packed
     return make_packed(e, t->f(), nullptr, N, K, out);
 }
 
+static int alloc_state_words(mellow_engine* e);
 extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     if (!e) return fail("null engine");
     if (e->finalized) return 0;
@@ -870,7 +873,14 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(upload(e, &e->rope_cos, c.data(), c.size()));
         CHK(upload(e, &e->rope_sin, s.data(), s.size()));
     }
-    // decode state words
+    CHK(alloc_state_words(e));
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+// per-context device words of the generation loop (position, stop bookkeeping, block liveness) + the mapped progress word
+static int alloc_state_words(mellow_engine* e) {
     HIPCHK(hipMalloc(&e->d_tokens, 4096 * sizeof(int32_t)));
     HIPCHK(hipMemset(e->d_tokens, 0, 4096 * sizeof(int32_t)));
     e->d_step = e->d_tokens + 1024;
@@ -887,8 +897,6 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_progress), 64, hipHostMallocMapped | hipHostMallocCoherent));
     *e->h_progress = 0;
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_progress), e->h_progress, 0));
-    e->host.clear();
-    e->finalized = true;
     return 0;
 }
 
@@ -1989,6 +1997,40 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     }
     return 0;
 }
+// A second execution context on the same device that SHARES the parent's weights (read-only after finalize): own HIP stream,
+// own workspaces, KV pages, decode buffers, captured graphs and loop words.  Calls on the two handles may overlap from
+// different host threads (mellow_amd/serve.py).  The parent must outlive its forks.
+int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
+    if (!parent || !out) return fail("null argument");
+    if (!parent->finalized) return fail("fork needs a finalized engine");
+    HIPCHK(hipSetDevice(parent->device));
+    HIPCHK(hipStreamSynchronize(parent->stream));
+    mellow_engine* c = new mellow_engine();
+    c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
+    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
+    // weight pointers (device memory owned by the parent)
+    c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;
+    c->bn_alpha = parent->bn_alpha; c->bn_beta = parent->bn_beta;
+    c->pe_w = parent->pe_w; c->pe_b = parent->pe_b; c->pe_nw = parent->pe_nw; c->pe_nb = parent->pe_nb;
+    for (int i = 0; i < 4; ++i) c->blocks[i] = parent->blocks[i];
+    for (int i = 0; i < 3; ++i) c->merge[i] = parent->merge[i];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) c->win_map[i][j] = parent->win_map[i][j];
+    c->fn_w = parent->fn_w; c->fn_b = parent->fn_b;
+    c->tscam = parent->tscam; c->c2l = parent->c2l; c->lin1 = parent->lin1; c->lin2 = parent->lin2;
+    c->tscam_b = parent->tscam_b; c->c2l_b = parent->c2l_b; c->pln_w = parent->pln_w; c->pln_b = parent->pln_b;
+    c->emb_row_map = parent->emb_row_map;
+    c->embed = parent->embed; c->lm_head = parent->lm_head; c->layers = parent->layers; c->final_norm = parent->final_norm;
+    c->rope_cos = parent->rope_cos; c->rope_sin = parent->rope_sin;
+    c->head8 = parent->head8; c->head_sc = parent->head_sc;
+    c->bf_w = parent->bf_w; c->fp8_w = parent->fp8_w;
+    c->resample_banks = parent->resample_banks;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev_phase[i]));
+    CHK(alloc_state_words(c));
+    *out = c;
+    return 0;
+}
+
 int mellow_set_graph(mellow_engine_t* e, int on) {
     if (!e) return fail("null engine");
     e->use_graph = on != 0;

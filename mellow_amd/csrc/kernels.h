@@ -103,6 +103,8 @@ constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention, m
 #endif
 #ifndef MELLOW_Q2_WAVES
 #define MELLOW_Q2_WAVES 12
+#else
+#define MELLOW_Q2_WAVES_FORCED 1
 #endif
 constexpr int Q2_HC = MELLOW_Q2_HC, Q2_WAVES = MELLOW_Q2_WAVES;
 constexpr int Q2_NPQ = 2 + Q2_HC;             // qkv slabs the fused kernel emits: 2 chunks of x_mid + Q2_HC chunks of h

@@ -59,6 +59,7 @@ def load_library(path: Optional[str] = None):
         "mellow_device_count": (ci, []),
         "mellow_engine_create": (ci, [P(MellowConfig), ci, P(vp)]),
         "mellow_engine_destroy": (None, [vp]),
+        "mellow_engine_fork": (ci, [vp, P(vp)]),
         "mellow_engine_load_tensor": (ci, [vp, C.c_char_p, vp, P(i64), ci, ci]),
         "mellow_engine_finalize": (ci, [vp]),
         "mellow_engine_num_required": (ci, []),
@@ -105,7 +106,7 @@ def load_library(path: Optional[str] = None):
 
 EXPORTED_SYMBOLS = (
     "mellow_abi_version", "mellow_last_error", "mellow_device_count", "mellow_engine_create",
-    "mellow_engine_destroy", "mellow_engine_load_tensor", "mellow_engine_finalize",
+    "mellow_engine_destroy", "mellow_engine_fork", "mellow_engine_load_tensor", "mellow_engine_finalize",
     "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
@@ -165,8 +166,24 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for f in getattr(self, "_forks", []):
+                f.close()
             self.lib.mellow_engine_destroy(self.h)
             self.h = None
+
+    def fork(self) -> "Engine":
+        """Another execution context on the same device sharing this engine's weights (mellow_engine_fork): own stream, KV pages,
+        workspaces and graphs; calls on the two objects may overlap from different threads.  Closed with (or before) its parent."""
+        if not self.finalized:
+            raise EngineError("fork needs a loaded engine")
+        c = object.__new__(Engine)
+        c.lib, c.lm, c.device, c.tdev, c.cfg, c.precision, c.finalized = self.lib, self.lm, self.device, self.tdev, self.cfg, self.precision, True
+        h = C.c_void_p()
+        self._chk(self.lib.mellow_engine_fork(self.h, C.byref(h)))
+        c.h = h
+        c._parent = self              # keeps the weights alive
+        self._forks = getattr(self, "_forks", []) + [c]
+        return c
 
     def __del__(self):
         try:

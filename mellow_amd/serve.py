@@ -2,8 +2,8 @@
 
 Why: a decode step is a chain of ~150 small dependent launches that leaves most of the chip idle, while the
 encoder / prefill phases are dense MFMA work.  Two or three independent contexts (own stream, own activation and
-KV buffers, own weight copy) overlap those phases of different batches; measured on one MI355X at B = 32 per batch:
-1 context 322 responses/s, 2 contexts 394, 3 contexts 446 (tools/concurrency_probe.py).  Latency of a single
+KV buffers; ONE shared weight copy: `Engine.fork` / `mellow_engine_fork`) overlap those phases of different batches; bench.py
+--inflight N reports the measured rate as its supplementary `pipelined` object.  Latency of a single
 batch gets worse (contention), so this is a throughput mode for a serving front-end, not the default path and not
 what bench.py reports as `value`.
 
@@ -25,20 +25,18 @@ class EnginePool:
     """`n_contexts` engines on one device; `generate_many` pipelines a list of batches over them."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_contexts: int = 2, device: int = 0,
-                 max_positions: int = 1024, lm: Optional[LMConfig] = None):
+                 max_positions: int = 2048, lm: Optional[LMConfig] = None, precision: str = "f32"):
         if n_contexts < 1:
             raise ValueError("n_contexts must be >= 1")
-        self.engines: List[Engine] = []
-        for _ in range(n_contexts):
-            e = Engine(lm=lm, device=device, max_positions=max_positions)
-            e.load_state_dict(state_dict)
-            self.engines.append(e)
+        first = Engine(lm=lm, device=device, max_positions=max_positions, precision=precision)
+        first.load_state_dict(state_dict)
+        self.engines: List[Engine] = [first] + [first.fork() for _ in range(n_contexts - 1)]      # one weight arena, N contexts
         self._locks = [threading.Lock() for _ in self.engines]
         self._pool = ThreadPoolExecutor(max_workers=n_contexts)
 
     def close(self):
         self._pool.shutdown(wait=True)
-        for e in self.engines:
+        for e in reversed(self.engines):      # forks before their parent
             e.close()
         self.engines = []
 

@@ -721,11 +721,18 @@ def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
 
 
 def test_pipelined_contexts_give_identical_tokens(engine_f32, synth_sd):
-    """mellow_amd.serve.EnginePool: two contexts on one GPU, batches in flight concurrently == one engine, batch by batch."""
+    """mellow_amd.serve.EnginePool: three contexts on one GPU sharing one weight copy, batches in flight concurrently == one engine,
+    batch by batch."""
     from mellow_amd.serve import EnginePool
-    pool = EnginePool(synth_sd, n_contexts=2, device=0)
-    batches = [synth.make_batch(3, first=3 * i) for i in range(4)]
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    pool = EnginePool(synth_sd, n_contexts=3, device=0)
+    batches = [synth.make_batch(3, first=3 * i) for i in range(6)]
     got = pool.generate_many(batches, max_len=6, stop_id=0, ignore_stop=True)
+    free1, _ = torch.cuda.mem_get_info(0)
+    # the contexts share ONE weight arena (mellow_engine_fork): three separate engines would hold > 10 GB
+    assert free0 - free1 < 5.5e9, (free0 - free1) / 1e9
+    assert pool.engines[1]._parent is pool.engines[0] and pool.engines[2]._parent is pool.engines[0]
     pool.close()
     for (a1, a2, ids), res in zip(batches, got):
         want, *_ = engine_f32.generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
