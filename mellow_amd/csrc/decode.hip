@@ -419,8 +419,43 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
     }
     __syncthreads();
     kstamp(1, 5, dbg);
-    if (tid < 48) {
-        // thread -> (head hh, dim quad dq): merged float4 of the 8 waves (+ the new key on the last split)
+    static_assert(DA_WAVES == 8 || DA_WAVES == 16, "the merge below reduces over 8-lane groups");
+    if (DA_WAVES == 8 && tid < 384) {
+        // thread -> (pair = (head hh, dim quad dq), wave w): the 8 waves' partials of a pair sit in 8 adjacent lanes and are
+        // combined with three DPP steps (xor 1, xor 2, mirror of the 8-lane half-row) instead of a serial loop in 48 threads
+        const int w = tid & 7, pair = tid >> 3, hh = pair >> 4, dq = pair & 15;
+        const float mw = mred[w * 3 + hh];
+        const float snew = snew_s[hh];
+        float M = mw;
+        M = fmaxf(M, dpp_mov<0xB1>(M));
+        M = fmaxf(M, dpp_mov<0x4E>(M));
+        M = fmaxf(M, dpp_mov<0x141>(M));
+        if (sp == DEC_TS - 1) M = fmaxf(M, snew);          // the last split also owns the new key
+        const float f = M > -INFINITY ? fast_exp(mw - M) : 0.f;      // waves without keys: m = -inf -> factor 0; an empty split: all 0
+        const float4 ow = *reinterpret_cast<const float4*>(ored + (w * 3 + hh) * 64 + dq * 4);
+        float L = lred[w * 3 + hh] * f;
+        float4 O = make_float4(ow.x * f, ow.y * f, ow.z * f, ow.w * f);
+#define MELLOW_R8(V) V += dpp_mov<0xB1>(V); V += dpp_mov<0x4E>(V); V += dpp_mov<0x141>(V)
+        MELLOW_R8(L); MELLOW_R8(O.x); MELLOW_R8(O.y); MELLOW_R8(O.z); MELLOW_R8(O.w);
+#undef MELLOW_R8
+        if (w == 0) {
+            if (sp == DEC_TS - 1 && M > -INFINITY) {
+                const float pn = fast_exp(snew - M);
+                const float4 vn = *reinterpret_cast<const float4*>(vnew + dq * 4);
+                L += pn;
+                O.x += pn * vn.x; O.y += pn * vn.y; O.z += pn * vn.z; O.w += pn * vn.w;
+            }
+            // F16-layout (B operand of the o_proj's 16x16x4 MFMA): column k = head*64 + 4*dq
+            const int head = 3 * g + hh, k = head * 64 + dq * 4;
+            const int rb = b >> 5, m = b & 31;
+            const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
+            reinterpret_cast<float4*>(a.attF16)[o4] = O;
+            if (dq == 0)      // (m, l) of this split: [head][row][split] pairs, so that the o_proj reads both splits of a row with one 16-byte load
+                *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
+        }
+    }
+    if (DA_WAVES != 8 && tid < 48) {
+        // thread -> (head hh, dim quad dq): merged float4 of the waves (+ the new key on the last split), serial form
         const int hh = tid >> 4, dq = tid & 15;
         const float snew = snew_s[hh];
         float M = sp == DEC_TS - 1 ? snew : -INFINITY;   // the last split also owns the new key
@@ -443,15 +478,12 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
                 O.x += ow.x * f; O.y += ow.y * f; O.z += ow.z * f; O.w += ow.w * f;
             }
         }
-        // F16-layout (B operand of the o_proj's 16x16x4 MFMA): column k = head*64 + 4*dq
         const int head = 3 * g + hh, k = head * 64 + dq * 4;
         const int rb = b >> 5, m = b & 31;
         const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
         reinterpret_cast<float4*>(a.attF16)[o4] = O;
-        if (dq == 0) {
-            a.att_m[((int64_t)sp * 9 + head) * a.rows + b] = M;
-            a.att_l[((int64_t)sp * 9 + head) * a.rows + b] = L;
-        }
+        if (dq == 0)
+            *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
     }
     kstamp(1, 6, dbg);
 }
@@ -506,10 +538,16 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
 #pragma unroll
         for (int s = 0; s < DEC_TS; ++s) {
             ms[i][s] = 0.f; ls[i][s] = 1.f; os[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);     // rows of another workgroup: x = 0
-            if (lrow) {
-                ms[i][s] = a.att_m[((int64_t)s * 9 + h) * a.rows + row];
-                ls[i][s] = a.att_l[((int64_t)s * 9 + h) * a.rows + row];
-                os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
+            if (lrow) os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
+        }
+        if (lrow) {
+            const float* mlp = a.att_ml + ((int64_t)h * a.rows + row) * DEC_TS * 2;
+            if constexpr (DEC_TS == 2) {                     // (m, l) of both splits of the row: one 16-byte load
+                const float4 v = *reinterpret_cast<const float4*>(mlp);
+                ms[i][0] = v.x; ls[i][0] = v.y; ms[i][1] = v.z; ls[i][1] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < DEC_TS; ++s) { ms[i][s] = mlp[2 * s]; ls[i][s] = mlp[2 * s + 1]; }
             }
         }
     }

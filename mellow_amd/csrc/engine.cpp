@@ -1159,7 +1159,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
         const size_t o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x);
         const size_t o_dslabF = take(DEC_KC_DOWN * n_x), o_ssq1 = take((size_t)Bp * DEC_KC_QKV), o_rope = take(64);
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
-        const size_t o_att = take((size_t)DEC_TS * n_x), o_am = take((size_t)DEC_TS * 9 * Bp), o_al = take((size_t)DEC_TS * 9 * Bp);
+        const size_t o_att = take((size_t)DEC_TS * n_x), o_aml = take((size_t)DEC_TS * 9 * Bp * 2);
         const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 256), o_xmidF16 = take(n_x);
         const bool fresh = e->dec.cap < off;
         CHK(ensure(e, e->dec, off));
@@ -1193,7 +1193,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
             }
             a.gs = gs;
         }
-        a.pq = p + o_pq; a.attF16 = p + o_att; a.att_m = p + o_am; a.att_l = p + o_al; a.ssq = p + o_ssq; a.guF = p + o_gu; a.xmidF16 = p + o_xmidF16;
+        a.pq = p + o_pq; a.attF16 = p + o_att; a.att_ml = p + o_aml; a.ssq = p + o_ssq; a.guF = p + o_gu; a.xmidF16 = p + o_xmidF16;
         a.logits = e->dlogits.p; a.cand_val = e->cand.p; a.cand_idx = reinterpret_cast<int32_t*>(e->cand.p + (size_t)Bp * (V / 32));
     }
     if (Bp > 1024) return fail("batch too large for the decode state block");

@@ -130,7 +130,7 @@ struct DecArgs {
     int64_t slabF_stride4 = 0;     // float4 elements between F-layout slabs
     float* pq = nullptr;           // qkv split-K slabs [DEC_KC_QKV][rows][960]
     float* attF16 = nullptr;       // attention partial outputs [DEC_TS][RB][36][2][64][4] (F16-layout)
-    float* att_m = nullptr; float* att_l = nullptr;     // [DEC_TS][9][rows]
+    float* att_ml = nullptr;       // (running max, sum of weights) of every key split: [9 heads][rows][DEC_TS][2]
     float* ssq = nullptr;          // [rows][40] per-o_proj-tile sums of squares of x_mid
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)

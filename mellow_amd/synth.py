@@ -106,8 +106,24 @@ def shifted_window_mask(res: int):
 
 
 # ---- synthetic state_dict ---------------------------------------------------------------------------
-def make_state_dict(seed: int = 0, lm: LMConfig | None = None) -> "OrderedDict[str, torch.Tensor]":
-    """Deterministic synthetic checkpoint with the real key layout."""
+def _decaying_spectrum(g: np.random.Generator, shape, std: float, alpha: float) -> np.ndarray:
+    """A matrix of the given shape and element std whose singular values fall off like i^-alpha (a product of two Gaussian
+    factors around a decaying diagonal): what trained weight matrices look like, unlike an i.i.d. Gaussian's flat spectrum."""
+    n, k = int(shape[0]), int(np.prod(shape[1:]))
+    r = min(n, k)
+    sv = (1.0 + np.arange(r, dtype=np.float64)) ** (-alpha)
+    a = (g.standard_normal((n, r)).astype(np.float32) * sv[None, :].astype(np.float32)) @ g.standard_normal((r, k)).astype(np.float32)
+    a *= np.float32(std / max(float(a.std()), 1e-30))
+    return a.reshape(shape)
+
+
+def make_state_dict(seed: int = 0, lm: LMConfig | None = None, structured: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic synthetic checkpoint with the real key layout.
+
+    structured=True (a DIFFERENT checkpoint, used only to put a number on the fp8 mode): every learned matrix
+    keeps its scale but gets a decaying singular spectrum (sigma_i ~ i^-1) instead of an i.i.d. Gaussian's flat one, and the
+    norm scales are exactly 1 -- closer to a trained network, where a quantisation error does not get re-amplified by every
+    layer.  The goldens and every parity test use the default (structured=False)."""
     lm = lm or LMConfig()
     layout = spec.state_dict_layout(lm)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -162,6 +178,12 @@ def make_state_dict(seed: int = 0, lm: LMConfig | None = None) -> "OrderedDict[s
             a = (g.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
         else:
             raise KeyError(f"no synthetic rule for {key}")
+        if structured and a is not None and a.dtype == np.float32:
+            frozen = key.endswith(("conv_real.weight", "conv_imag.weight", "melW", "attn_mask", "running_mean", "running_var"))
+            if leaf == "weight" and len(shape) >= 2 and not frozen:
+                a = _decaying_spectrum(_rng(seed + 7919, key), shape, float(a.std()), 1.0).astype(np.float32)
+            elif leaf == "weight" and len(shape) == 1 and key != spec.LM + "model.norm.weight":
+                a = np.ones(shape, dtype=np.float32)
         if a is not None:
             assert tuple(a.shape) == tuple(shape), (key, a.shape, shape)
             sd[key] = torch.from_numpy(np.ascontiguousarray(a)).reshape(shape)

@@ -730,8 +730,9 @@ def test_pipelined_contexts_give_identical_tokens(engine_f32, synth_sd):
     batches = [synth.make_batch(3, first=3 * i) for i in range(6)]
     got = pool.generate_many(batches, max_len=6, stop_id=0, ignore_stop=True)
     free1, _ = torch.cuda.mem_get_info(0)
-    # the contexts share ONE weight arena (mellow_engine_fork): three separate engines would hold > 10 GB
-    assert free0 - free1 < 5.5e9, (free0 - free1) / 1e9
+    # the contexts share ONE weight arena (mellow_engine_fork; 3.4 GB reserved) + per-context workspaces (measured 6.1 GB in
+    # all): three separate engines would hold > 10 GB in arenas alone
+    assert free0 - free1 < 8e9, (free0 - free1) / 1e9
     assert pool.engines[1]._parent is pool.engines[0] and pool.engines[2]._parent is pool.engines[0]
     pool.close()
     for (a1, a2, ids), res in zip(batches, got):

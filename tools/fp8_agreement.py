@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
-sd = synth.make_state_dict(0)
+STRUCT = len(sys.argv) > 1 and sys.argv[1] == "structured"
+sd = synth.make_state_dict(0, structured=STRUCT)
+print("checkpoint:", "structured (decaying singular spectrum)" if STRUCT else "default (i.i.d. Gaussian)")
 e32 = Engine(device=0, max_positions=1024)
 e32.load_state_dict(sd)
 e8 = Engine(device=0, max_positions=1024, precision="fp8")
