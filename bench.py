@@ -14,7 +14,8 @@ inputs already resident in HBM.  Weights: seeded synthetic checkpoint with the r
 32 examples and the token ids are all-gathered once per step over RCCL.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     dominant kernel family (fp32 MFMA GEMM) measured with HIP events on the engine's stream
+  roofline     the dominant phase by time, the decode step (HBM-bound): algorithmic bytes / step time, + PMC traffic per step
+  roofline_gemm  the dominant family by FLOPs (dense GEMMs of encoder + prefill, MFMA-bound), HIP events on the engine's stream
   cpu_baseline the oracle (op-for-op CPU port of the reference: no KV cache) timed on a bounded sample (N = 1 only)
 """
 from __future__ import annotations
@@ -36,7 +37,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 matrix peak (same guide); the 32x32x16 fp8 form used here sustains 2460
 PEAK_HBM_GBS = 8000.0
 PEAK_F32X3_TFLOPS = 2500.0 / 6.0   # f32x3 mode: six bf16 MFMA products per fp32 product on the 2.5 PF dense bf16 pipe
-PMC_TRAFFIC_FILE = "r02_pmc_gemm_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_gemm_traffic.json"          # dense GEMM family (tools/pmc_traffic.py gemm)
+PMC_DECODE_FILE = "r03_pmc_decode_traffic.json"         # decode step (tools/pmc_traffic.py decode)
 FFT_GFLOP_PER_CLIP = 0.051         # algorithmic cost of the STFT; the kernel runs it as a dense DFT GEMM (2.10 GF/clip)
 
 # algorithmic work per response at max_len = 64, prefix 389
@@ -62,6 +64,23 @@ def kernel_source_sha16() -> str:
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def committed_pmc(fname: str, precision: str, key: str):
+    """HBM-side traffic from a committed rocprofv3 PMC result (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read
+    correction applied: /opt/skills/guides/MI355X_MICROARCH.md): it cannot be sampled from inside this process.  The file
+    carries a hash of the kernel sources and the numeric mode; a result measured on other sources is never printed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", fname)) as f:
+            pj = json.load(f)
+    except Exception:
+        return None, f"no PMC result committed (profiles/{fname})"
+    if pj.get("precision", "f32x3") != precision:
+        return None, f"profiles/{fname} was measured in the {pj.get('precision', 'f32x3')} mode, this run is {precision}: not printed"
+    if pj.get("source_sha16") != kernel_source_sha16():
+        return None, (f"profiles/{fname} was measured on other kernel sources (sha {pj.get('source_sha16')} != "
+                      f"{kernel_source_sha16()}): not printed; regenerate with tools/collect_profiles.sh")
+    return round(pj[key]), f"bytes (memory-side, PMC, profiles/{fname}, same kernel sources)"
 
 
 def decode_algorithmic_bytes(B: int, L: int, T0: int = 389) -> float:
@@ -377,23 +396,8 @@ def main():
     eng.prof_enable(False)
 
     if rank == 0:
-        # HBM-side traffic of the dominant kernel comes from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-        # in separate runs, gfx950 x2 read correction applied): it cannot be sampled from inside this process
-        traffic, traffic_note = None, "no PMC result committed for the current kernel sources"
-        try:
-            with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
-                pj = json.load(f)
-            if pj.get("precision", "f32x3") != args.precision:
-                traffic_note = (f"profiles/{PMC_TRAFFIC_FILE} was measured in the {pj.get('precision', 'f32x3')} mode, this run is "
-                                f"{args.precision}: not printed")
-            elif pj.get("source_sha16") == kernel_source_sha16():
-                traffic = round(pj["traffic_bytes_per_launch"])
-                traffic_note = f"bytes per launch (memory-side, PMC, profiles/{PMC_TRAFFIC_FILE}, same kernel sources)"
-            else:
-                traffic_note = (f"profiles/{PMC_TRAFFIC_FILE} was measured on other kernel sources (sha {pj.get('source_sha16')} "
-                                f"!= {kernel_source_sha16()}): not printed; regenerate with tools/pmc_prefill.py + tools/pmc_traffic.py")
-        except Exception:
-            pass
+        traffic, traffic_note = committed_pmc(PMC_TRAFFIC_FILE, args.precision, "traffic_bytes_per_launch")
+        dec_traffic, dec_traffic_note = committed_pmc(PMC_DECODE_FILE, args.precision, "traffic_bytes_per_step")
         total = n_gpus * B * args.steps
         value = total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
@@ -429,7 +433,7 @@ def main():
             "env": mellow_env,
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
-            "roofline": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
+            "roofline_gemm": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
                                     if fp8 else "gemm_x3q_kernel (LM prefill) + gemm_x3p_kernel (encoder): 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
                                     "mel on gemm_x3p_kernel too, the STFT as an FFT (stft_fft_power_kernel, counted in this family); peak = 2.5 PF dense bf16 / 6" if args.precision == "f32x3"
                                     else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),
@@ -441,19 +445,26 @@ def main():
                          "achieved_dense_dft": round(tf_dense, 2),
                          "note": "achieved = algorithmic flops (STFT priced as an FFT, SURVEY 8d) / family time measured live with "
                                  "HIP events on the engine's stream; achieved_dense_dft counts the DFT GEMM's own flops"},
-            "roofline_decode": {"kernels": "dec_qkv | dec_attn | dec_oproj | dec_gateup16 | dec_down x 30 + final norm, lm_head, arg-max "
-                                           "per step (hipGraph replay)",
-                                "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(dec_gbs / PEAK_HBM_GBS, 4), "steps": L - 1,
-                                "ms_per_step": round(phases["decode_ms"] / max(1, L - 1), 4),
-                                "bytes_per_step_avg": round(dec_bytes / max(1, L - 1)),
-                                "note": "algorithmic bytes (538.06 MB fp32 weights + 46,080 B per cached token per example, SURVEY 8d) "
-                                        "/ decode phase time (HIP events, timed pass)"},
+            "roofline": None,
             "path_roofline": {"t_roof_ms_per_step": round(t_roof * 1e3, 3),
                               "frac": round(t_roof * 1e3 / ms_per_step, 4),
                               "definition": "F_dense/P_mfma(dtype) + Bytes_decode/8TB/s per response x batch (SURVEY 8d)"},
             "kernel_families_ms": {k: round(v["ms"], 3) for k, v in rep.items()},
         }
+        # the dominant part of the pass by time is the decode phase (hipGraph replays of one step = one "launch" of 124 kernels):
+        # HBM-bound, priced by the ALGORITHMIC bytes of SURVEY 8d; `traffic` = what the memory side actually moved per step (PMC)
+        out["roofline"] = {
+            "kernel": "one decode step (hipGraph replay): dec_qkv + 30 x dec_attn + 30 x (dec_oproj | dec_gateup16) + 29 x dec_qkv2 + dec_down "
+                      "+ final norm, lm_head, arg-max; the dominant phase of the pass by time",
+            "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(dec_gbs / PEAK_HBM_GBS, 4), "traffic": dec_traffic, "traffic_unit": dec_traffic_note + " per step",
+            "launches": L - 1, "avg_launch_us": round(phases["decode_ms"] * 1e3 / max(1, L - 1), 2),
+            "bytes_per_launch": round(dec_bytes / max(1, L - 1)),
+            "share_of_pass": round(phases["decode_ms"] / ms_per_step, 3),
+            "note": "achieved = algorithmic bytes per step (538.06 MB of fp32 weights + 46,080 B per cached token per example, SURVEY 8d) "
+                    "/ average step time, HIP events around the decode phase of the timed pass on the engine's stream",
+        }
+        out["roofline_decode"] = out["roofline"]                 # the name earlier rounds used
         if ref_sem is not None:
             out["reference_semantics"] = ref_sem
         if pcie is not None:

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 counter-collection CSVs (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass of
-tools/pmc_prefill.py) into the per-launch memory-side traffic of the gemm_f32_kernel family
-(profiles/rNN_pmc_gemm_traffic.json).  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 x2 correction of
+"""Turn two rocprofv3 counter-collection CSVs (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass) into the memory-side traffic
+of a kernel family (profiles/rNN_pmc_*_traffic.json).  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 x2 correction of
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section: 128-B read requests tallied at 64 B) is applied to reads.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+    python tools/pmc_traffic.py gemm   <fetch.csv> <write.csv> <out.json>     workload tools/pmc_prefill.py  -> bytes per GEMM launch
+    python tools/pmc_traffic.py decode <fetch.csv> <write.csv> <out.json>     workload tools/decode_probe.py -> bytes per decode step"""
 import csv
 import json
 import os
@@ -13,34 +13,59 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16  # noqa: E402  (bench.py refuses to print a result measured on other kernel sources)
 
+GEMM = ("gemm_f32_kernel", "gemm_x3p_kernel", "gemm_x3q_kernel", "gemm_bf16x3f_kernel", "stft_fft_power_kernel")
+DECODE = ("dec_qkv_kernel", "dec_qkv2_kernel", "dec_attn_kernel", "dec_oproj_kernel", "dec_gateup16_kernel", "dec_down_kernel",
+          "dec_final_norm_kernel", "dec_fullk_kernel", "dec_argmax_kernel", "dec_compact_kernel")
 
-def family(path, counter):
-    n, tot = 0, 0.0
+
+def family(path, counter, names):
+    per = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and ("gemm_f32_kernel" in r["Kernel_Name"] or "gemm_x3p_kernel" in r["Kernel_Name"] or "gemm_x3q_kernel" in r["Kernel_Name"]
-                                             or "gemm_bf16x3f_kernel" in r["Kernel_Name"] or "stft_fft_power_kernel" in r["Kernel_Name"]):
-            n += 1
-            tot += float(r["Counter_Value"])
-    return n, tot
+        if r["Counter_Name"] != counter:
+            continue
+        k = next((n for n in names if n in r["Kernel_Name"]), None)
+        if k is None:
+            continue
+        a = per.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return per
 
 
-nf, fetch = family(sys.argv[1], "FETCH_SIZE")
-nw, write = family(sys.argv[2], "WRITE_SIZE")
+mode, fpath, wpath, opath = sys.argv[1:5]
+names = GEMM if mode == "gemm" else DECODE
+pf, pw = family(fpath, "FETCH_SIZE", names), family(wpath, "WRITE_SIZE", names)
+nf, fetch = sum(v[0] for v in pf.values()), sum(v[1] for v in pf.values())
+nw, write = sum(v[0] for v in pw.values()), sum(v[1] for v in pw.values())
 assert nf == nw and nf > 0, (nf, nw)
 out = {
-    "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill) / gemm_x3p_kernel / gemm_bf16x3f_kernel (f32x3 mode) + gemm_f32_kernel (all instances) + stft_fft_power_kernel (the STFT of the f32x3 mode)",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py "
-              "(2 encoder+prefill passes at B=32, in the `precision` mode below); reduced with tools/pmc_traffic.py",
     "source_sha16": kernel_source_sha16(),
-    "precision": os.environ.get("MELLOW_PRECISION", "f32x3"),      # the mode tools/pmc_prefill.py ran in
+    "precision": os.environ.get("MELLOW_PRECISION", "f32x3"),      # the mode the workload ran in
     "launches": nf,
-    "fetch_size_kb_per_launch": fetch / nf,
-    "write_size_kb_per_launch": write / nw,
-    "fetch_bytes_per_launch_x2_corrected": 2.0 * fetch * 1024.0 / nf,
-    "write_bytes_per_launch": write * 1024.0 / nw,
-    "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / nf,
     "note": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section): doubled; "
             "memory-side requests include Infinity-Cache hits",
+    "per_kernel_bytes_per_launch": {k: round((2.0 * pf[k][1] + pw.get(k, [0, 0.0])[1]) * 1024.0 / pf[k][0]) for k in pf},
 }
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+if mode == "gemm":
+    out.update({
+        "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill) / gemm_x3p_kernel / gemm_bf16x3f_kernel "
+                  "(f32x3 mode) + gemm_f32_kernel (all instances) + stft_fft_power_kernel (the STFT of the f32x3 mode)",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py (2 encoder+prefill passes at "
+                  "B=32, in the `precision` mode); reduced with tools/pmc_traffic.py gemm",
+        "fetch_bytes_per_launch_x2_corrected": 2.0 * fetch * 1024.0 / nf,
+        "write_bytes_per_launch": write * 1024.0 / nw,
+        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / nf,
+    })
+else:
+    steps = pf["dec_fullk_kernel"][0]          # one lm_head launch per decode step (the prefill's last-position step included)
+    out.update({
+        "kernel": "every kernel of the decode step (dec_*), summed per step",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/decode_probe.py (4 passes of B=32, "
+                  "max_len 64: 256 steps, contexts 389..452); reduced with tools/pmc_traffic.py decode",
+        "steps": steps,
+        "fetch_bytes_per_step_x2_corrected": 2.0 * fetch * 1024.0 / steps,
+        "write_bytes_per_step": write * 1024.0 / steps,
+        "traffic_bytes_per_step": (2.0 * fetch + write) * 1024.0 / steps,
+    })
+json.dump(out, open(opath, "w"), indent=1)
 print(json.dumps(out))
