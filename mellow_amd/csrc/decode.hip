@@ -192,6 +192,10 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
 #define MELLOW_DA_WAVES 8
 #define MELLOW_DA_G 7
 #endif
+#ifndef MELLOW_DA_MINW
+#define MELLOW_DA_MINW 4      // waves per SIMD the register allocation must allow: 4 = two 8-wave workgroups per CU (128 VGPRs), so that
+#endif                        // the 384 workgroups of a 64-row batch are resident together instead of in two rounds
+constexpr int DA_MINW = MELLOW_DA_WAVES == 8 ? MELLOW_DA_MINW : 1;
 constexpr int DA_WAVES = MELLOW_DA_WAVES;
 constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chunk covers 2 * DA_WAVES * DA_G * 4 = 448 keys
 #ifndef MELLOW_DA_G1
@@ -203,8 +207,11 @@ constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key group
 // projected values arrive as Q2_NPQ slabs, and x_new = x_mid + sum of the Q2_HC down slabs is formed HERE (the 144 float4 of the
 // row, by every workgroup of the row: its sum of squares is the RMS statistic; the (kv head 0, split 0) workgroup also writes the
 // row for the o_proj's residual).  !FUSED: the producer was dec_qkv_kernel (first layer of a step: 8 slabs + its own statistic).
-template <bool BLK, bool FUSED>
-__global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
+// ONE: the launch has a single 32-row block (192 workgroups: one per CU, registers are free) -> the chunk loop in its plain form
+//      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
+//      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
+template <bool BLK, bool FUSED, bool ONE>
+__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
                                                                   float* __restrict__ v_cache) {
     __shared__ float ssq_part[3];
     __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
@@ -355,54 +362,76 @@ __global__ __launch_bounds__(DA_WAVES * 64) void dec_attn_kernel(const DecArgs a
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int g0 = gbeg + wave; g0 < ((MELLOW_DA_ABL & 2) ? gbeg : gend); g0 += DA_WAVES * DA_G) {
-        if (g0 != gbeg + wave) {           // later chunks (only for contexts beyond 448 keys): reload
-#pragma unroll
-            for (int u = 0; u < DA_G; ++u) {
-                const int gi = g0 + u * DA_WAVES;
-                const int tc = min(gi * 4 + sub, Tmax - 1);
-                k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
-                v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+    // one chunk = the DA_G key groups a wave holds in registers (masked by weight, exp(-inf) = 0: slots beyond the context hold
+    // finite values, engine.cpp clear_page_tails; the 16 dim-quads of a key are one DPP row).  The first chunk (every context
+    // up to 448 keys per split) works on the registers loaded above; further chunks (longer contexts) reload and repeat.
+    // Two code shapes around the same body (a macro, so that both are the literal source text):
+    //   ONE   the plain loop; the compiler keeps a second set of K/V registers alive across the back edge (220 VGPRs)
+    //   !ONE  the first chunk peeled by hand: 118 VGPRs, two workgroups per CU (DA_MINW)
+#define MELLOW_DA_CHUNK(g0)                                                                                              \
+    {                                                                                                                    \
+        float sc[DA_G][3];                                                                                               \
+        float cmax[3] = {-INFINITY, -INFINITY, -INFINITY};                                                               \
+_Pragma("unroll")                                                                                                        \
+        for (int u = 0; u < DA_G; ++u) {                                                                                 \
+            const int gi = g0 + u * DA_WAVES;                                                                            \
+            const int t = gi * 4 + sub;                                                                                  \
+            const bool ok = gi < gend && t < pos;                                                                        \
+_Pragma("unroll")                                                                                                        \
+            for (int hh = 0; hh < 3; ++hh) {                                                                             \
+                float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;            \
+                sv = row16_sum(sv);                                                                                      \
+                sv = ok ? sv : -INFINITY;                                                                                \
+                sc[u][hh] = sv;                                                                                          \
+                cmax[hh] = fmaxf(cmax[hh], sv);                                                                          \
+            }                                                                                                            \
+        }                                                                                                                \
+_Pragma("unroll")                                                                                                        \
+        for (int hh = 0; hh < 3; ++hh) {                                                                                 \
+            float cm = cmax[hh];                                                                                         \
+            cm = fmaxf(cm, swz_xor16(cm));                                                                               \
+            cm = half_max(cm);                                                                                           \
+            const float m_new = fmaxf(m_run[hh], cm);                                                                    \
+            const float alpha = fast_exp(m_run[hh] - m_new);                                                             \
+            m_run[hh] = m_new;                                                                                           \
+            float lsum = 0.f;                                                                                            \
+            float4 o = make_float4(acc[hh].x * alpha, acc[hh].y * alpha, acc[hh].z * alpha, acc[hh].w * alpha);          \
+_Pragma("unroll")                                                                                                        \
+            for (int u = 0; u < DA_G; ++u) {                                                                             \
+                const float p = fast_exp(sc[u][hh] - m_new);                                                             \
+                lsum += p;                                                                                               \
+                o.x += p * v4[u].x; o.y += p * v4[u].y; o.z += p * v4[u].z; o.w += p * v4[u].w;                          \
+            }                                                                                                            \
+            acc[hh] = o;                                                                                                 \
+            l_run[hh] = l_run[hh] * alpha + lsum;                                                                        \
+        }                                                                                                                \
+    }
+    const int g_first = gbeg + wave, g_stop = (MELLOW_DA_ABL & 2) ? gbeg : gend;
+#define MELLOW_DA_RELOAD(g0)                                                                                             \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < DA_G; ++u) {                                                               \
+            const int gi = (g0) + u * DA_WAVES;                                                                          \
+            const int tc = min(gi * 4 + sub, Tmax - 1);                                                                  \
+            k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));                        \
+            v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));                        \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    if constexpr (ONE) {
+        for (int g0 = g_first; g0 < g_stop; g0 += DA_WAVES * DA_G) {
+            if (g0 != g_first) MELLOW_DA_RELOAD(g0)        // later chunks (only for contexts beyond 448 keys per split)
+            MELLOW_DA_CHUNK(g0)
         }
-        float sc[DA_G][3];
-        float cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int u = 0; u < DA_G; ++u) {
-            const int gi = g0 + u * DA_WAVES;
-            const int t = gi * 4 + sub;
-            const bool ok = gi < gend && t < pos;
-            // masked by weight (exp(-inf) = 0): slots beyond the context hold finite values (engine.cpp clear_page_tails)
-#pragma unroll
-            for (int hh = 0; hh < 3; ++hh) {
-                float sv = q4[hh].x * k4[u].x + q4[hh].y * k4[u].y + q4[hh].z * k4[u].z + q4[hh].w * k4[u].w;
-                sv = row16_sum(sv);                  // the 16 dim-quads of a key are one DPP row
-                sv = ok ? sv : -INFINITY;
-                sc[u][hh] = sv;
-                cmax[hh] = fmaxf(cmax[hh], sv);
-            }
-        }
-#pragma unroll
-        for (int hh = 0; hh < 3; ++hh) {
-            float cm = cmax[hh];
-            cm = fmaxf(cm, swz_xor16(cm));
-            cm = half_max(cm);
-            const float m_new = fmaxf(m_run[hh], cm);       // finite: key 4*g0 of the chunk is valid
-            const float alpha = fast_exp(m_run[hh] - m_new);    // exp(-inf) = 0 on the first chunk
-            m_run[hh] = m_new;
-            float lsum = 0.f;
-            float4 o = make_float4(acc[hh].x * alpha, acc[hh].y * alpha, acc[hh].z * alpha, acc[hh].w * alpha);
-#pragma unroll
-            for (int u = 0; u < DA_G; ++u) {
-                const float p = fast_exp(sc[u][hh] - m_new);    // masked keys: exp(-inf) = 0
-                lsum += p;
-                o.x += p * v4[u].x; o.y += p * v4[u].y; o.z += p * v4[u].z; o.w += p * v4[u].w;
-            }
-            acc[hh] = o;
-            l_run[hh] = l_run[hh] * alpha + lsum;
+    } else {
+        if (g_first < g_stop) MELLOW_DA_CHUNK(g_first)
+#pragma clang loop unroll(disable)
+        for (int g0 = g_first + DA_WAVES * DA_G; g0 < g_stop; g0 += DA_WAVES * DA_G) {
+            MELLOW_DA_RELOAD(g0)
+            MELLOW_DA_CHUNK(g0)
         }
     }
+#undef MELLOW_DA_CHUNK
+#undef MELLOW_DA_RELOAD
     kstamp(1, 4, dbg && l_run[0] == l_run[0]);
     // reduce the 4 key-subs of the wave; publish (m, l, o) of the wave
 #pragma unroll
@@ -1128,10 +1157,14 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 }
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
     const dim3 grid(3, a.rows, DEC_TS), block(DA_WAVES * 64);
-    if (a.blk_live && fused) hipLaunchKernelGGL((dec_attn_kernel<true, true>), grid, block, 0, s, a, k_cache, v_cache);
-    else if (a.blk_live) hipLaunchKernelGGL((dec_attn_kernel<true, false>), grid, block, 0, s, a, k_cache, v_cache);
-    else if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true>), grid, block, 0, s, a, k_cache, v_cache);
-    else hipLaunchKernelGGL((dec_attn_kernel<false, false>), grid, block, 0, s, a, k_cache, v_cache);
+    // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)
+    if (a.RB == 1 && !a.blk_live) {
+        if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true, true>), grid, block, 0, s, a, k_cache, v_cache);
+        else hipLaunchKernelGGL((dec_attn_kernel<false, false, true>), grid, block, 0, s, a, k_cache, v_cache);
+    } else if (a.blk_live && fused) hipLaunchKernelGGL((dec_attn_kernel<true, true, false>), grid, block, 0, s, a, k_cache, v_cache);
+    else if (a.blk_live) hipLaunchKernelGGL((dec_attn_kernel<true, false, false>), grid, block, 0, s, a, k_cache, v_cache);
+    else if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true, false>), grid, block, 0, s, a, k_cache, v_cache);
+    else hipLaunchKernelGGL((dec_attn_kernel<false, false, false>), grid, block, 0, s, a, k_cache, v_cache);
 }
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
     // waves per workgroup: 4 x (9 | 12) k-tiles when there is one row block (a 4-way instead of a 12-way LDS reduction: 49.55 vs

@@ -6,14 +6,15 @@ R=r03
 O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 # --- PMC: HBM-side traffic of the GEMM family (per launch) and of the decode step (per step) ---
-rocprofv3 --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pw -o w --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o w --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
 python tools/pmc_traffic.py gemm $O/pf/f_counter_collection.csv $O/pw/w_counter_collection.csv $O/pmc_gemm_traffic.json
-rocprofv3 --pmc FETCH_SIZE -d $O/df -o f --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/dw -o w --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
+# (counter collection costs ~0.1 s per dispatch: the decode passes use a 5-step workload, tools/pmc_decode.py)
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/df -o f --output-format csv -- python tools/pmc_decode.py > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/dw -o w --output-format csv -- python tools/pmc_decode.py > /dev/null 2>&1
 python tools/pmc_traffic.py decode $O/df/f_counter_collection.csv $O/dw/w_counter_collection.csv $O/pmc_decode_traffic.json
 # --- PMC: MFMA utilisation of the GEMM family / attentions ---
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $O/pm -o m --output-format csv -- python tools/pmc_prefill.py > $O/pmc_mfma.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $O/pm -o m --output-format csv -- python tools/pmc_prefill.py > $O/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $O/pm/m_counter_collection.csv $O/pmc_gemm_mfma.json || tail -5 $O/pmc_mfma.log
 cp $O/pmc_gemm_traffic.json profiles/${R}_pmc_gemm_traffic.json     # bench.py prints `traffic` only from files whose source hash matches
 cp $O/pmc_decode_traffic.json profiles/${R}_pmc_decode_traffic.json
@@ -24,10 +25,10 @@ timeout 300 python bench.py --steps 5 --warmup 2 --precision fp8 --no-cpu-baseli
 timeout 300 python bench.py --steps 3 --warmup 1 --preset configs2 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_configs2.json 2>/dev/null
 timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_configs4.json 2>/dev/null
 # --- kernel trace + stats of the default command, decode timeline ---
-rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_under_rocprofv3.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_under_rocprofv3.json 2>/dev/null
 cp $O/stats/st_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || find $O/stats -name "*stats*.csv" | head
-rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
 python tools/trace_summary.py $O/trace_dec/tr_kernel_trace.csv 40 > $O/decode_step_timeline.txt 2>&1
-python tools/fp8_agreement.py structured 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement.txt
+timeout 400 python tools/fp8_agreement.py structured 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement.txt
 rm -rf $O/stats $O/pf $O/pw $O/df $O/dw $O/pm $O/trace_dec
 ls -la $O

@@ -4,7 +4,7 @@ of a kernel family (profiles/rNN_pmc_*_traffic.json).  FETCH_SIZE / WRITE_SIZE a
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section: 128-B read requests tallied at 64 B) is applied to reads.
 
     python tools/pmc_traffic.py gemm   <fetch.csv> <write.csv> <out.json>     workload tools/pmc_prefill.py  -> bytes per GEMM launch
-    python tools/pmc_traffic.py decode <fetch.csv> <write.csv> <out.json>     workload tools/decode_probe.py -> bytes per decode step"""
+    python tools/pmc_traffic.py decode <fetch.csv> <write.csv> <out.json>     workload tools/pmc_decode.py -> bytes per decode step"""
 import csv
 import json
 import os
@@ -60,8 +60,8 @@ else:
     steps = pf["dec_fullk_kernel"][0]          # one lm_head launch per decode step (the prefill's last-position step included)
     out.update({
         "kernel": "every kernel of the decode step (dec_*), summed per step",
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/decode_probe.py (4 passes of B=32, "
-                  "max_len 64: 256 steps, contexts 389..452); reduced with tools/pmc_traffic.py decode",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_decode.py (one call at B=32, max_len 6: "
+                  "the prefill's last-position step + 5 decode steps, contexts 389..393); reduced with tools/pmc_traffic.py decode",
         "steps": steps,
         "fetch_bytes_per_step_x2_corrected": 2.0 * fetch * 1024.0 / steps,
         "write_bytes_per_step": write * 1024.0 / steps,
