@@ -182,6 +182,13 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
 //   * V slots are stored at lane ^ ((lane >> 3) & 3): a lane group of the 16-byte store then covers 8 distinct bank quads
 //     (the plain order would put its 8 lanes on 2), and the read groups of ds_read_b128 stay conflict-free.
 // ----------------------------------------------------------------------------------------------------------------------------
+#ifndef MELLOW_PAX_LOADERS
+#define MELLOW_PAX_LOADERS 1      // 1: one wave stages K and V (1.88 ms per pass); 2: a wave each (2.34 ms, same box)
+#endif
+constexpr int PAX_LOADERS = MELLOW_PAX_LOADERS, PAX_THREADS = (3 + PAX_LOADERS) * 64;
+#ifndef MELLOW_PAX_MINW
+#define MELLOW_PAX_MINW 2      // waves per SIMD the register allocation must allow (2 workgroups of 4 waves per CU)
+#endif
 constexpr int PAX_K_SLOTS = 4 * 3 * 64, PAX_V_SLOTS = 2 * 2 * 3 * 64;
 __device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
 #define PAX_MFMA(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
@@ -189,7 +196,7 @@ __device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
 #define PAX_6(A0, A1, A2, B0, B1, B2, ACC) \
     do { PAX_MFMA(A2, B0, ACC); PAX_MFMA(A1, B1, ACC); PAX_MFMA(A0, B2, ACC); PAX_MFMA(A1, B0, ACC); PAX_MFMA(A0, B1, ACC); PAX_MFMA(A0, B0, ACC); } while (0)
 
-__global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
+__global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
                                                                    const float* __restrict__ v_cache, float* __restrict__ o,
                                                                    i32x4* __restrict__ o_apb, int T, int Tmax) {
     __shared__ i32x4 Kp[2][PAX_K_SLOTS];
@@ -199,12 +206,15 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
     const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
     const float* vpage = v_cache + ((int64_t)b * 3 + g) * Tmax * 64;
 
-    if (wave == 3) {
-        // ---------------- loader wave: 8 + 8 float4 per lane per tile, split, 12 + 12 sixteen-byte LDS stores ----------------
+    if (wave >= 3) {
+        // ---------------- loader waves: wave 3 stages K, wave 4 stages V (PAX_LOADERS == 2; one wave does both otherwise):
+        //                  8 float4 per lane per tile and operand, split, 12 sixteen-byte LDS stores ----------------
+        const bool doK = PAX_LOADERS == 1 || wave == 3, doV = PAX_LOADERS == 1 || wave == 4;
         f32x4 pk[8], pv[8];
         const int klo = lane & 7, oct = lane >> 3;               // K: keys klo + 8 i (i = 0..3), the 8 dims 8 oct .. 8 oct + 7
         const int q4 = lane & 15, t2 = (lane >> 4) & 1, hv = lane >> 5;     // V: dims 4 q4 .. + 3, key step t2, key half hv
         auto fetch = [&](int kt) {
+            if (doK)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int t = kt * 32 + klo + 8 * i;
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
                 pk[2 * i] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + oct * 8);
                 pk[2 * i + 1] = *reinterpret_cast<const f32x4*>(kpage + (int64_t)t * 64 + oct * 8 + 4);
             }
+            if (doV)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int t = kt * 32 + 16 * t2 + (j & 3) + 8 * (j >> 2) + 4 * hv;
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
             }
         };
         auto stage = [&](int st) {
+            if (doK)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v[8] = {pk[2 * i][0], pk[2 * i][1], pk[2 * i][2], pk[2 * i][3],
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
                 i32x4* dst = &Kp[st][((oct >> 1) * 3) * 64 + klo + 8 * i + 32 * (oct & 1)];
                 dst[0] = p0; dst[64] = p1; dst[128] = p2;
             }
+            if (doV)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v[8] = {pv[0][e], pv[1][e], pv[2][e], pv[3][e], pv[4][e], pv[5][e], pv[6][e], pv[7][e]};
@@ -279,14 +292,24 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
         const int k0 = kt * 32;
         const i32x4* Kc = Kp[kt & 1] + lane;
         const i32x4* Vc = Vp[kt & 1] + vl;
-        f32x16 S;
+        // two independent accumulation chains (d-steps 0,1 | 2,3), added at the end: a dependent 32x32x16 MFMA cannot issue
+        // before its predecessor's accumulator is back, so one chain of 24 runs at the latency, not at the issue rate
+        f32x16 S, S2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; S2[r] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
             const i32x4 a0 = Kc[(s * 3 + 0) * 64], a1 = Kc[(s * 3 + 1) * 64], a2 = Kc[(s * 3 + 2) * 64];
-            PAX_6(a0, a1, a2, qp[s][0], qp[s][1], qp[s][2], S);
+            const i32x4 c0 = Kc[((s + 2) * 3 + 0) * 64], c1 = Kc[((s + 2) * 3 + 1) * 64], c2 = Kc[((s + 2) * 3 + 2) * 64];
+            PAX_MFMA(a2, qp[s][0], S);      PAX_MFMA(c2, qp[s + 2][0], S2);
+            PAX_MFMA(a1, qp[s][1], S);      PAX_MFMA(c1, qp[s + 2][1], S2);
+            PAX_MFMA(a0, qp[s][2], S);      PAX_MFMA(c0, qp[s + 2][2], S2);
+            PAX_MFMA(a1, qp[s][0], S);      PAX_MFMA(c1, qp[s + 2][0], S2);
+            PAX_MFMA(a0, qp[s][1], S);      PAX_MFMA(c0, qp[s + 2][1], S2);
+            PAX_MFMA(a0, qp[s][0], S);      PAX_MFMA(c0, qp[s + 2][0], S2);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] += S2[r];
         // lane: query ql, keys k0 + (r&3) + 8(r>>2) + 4h
         float tmax = -INFINITY;
 #pragma unroll
@@ -316,13 +339,15 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
             const float v[8] = {p[8 * t], p[8 * t + 1], p[8 * t + 2], p[8 * t + 3], p[8 * t + 4], p[8 * t + 5], p[8 * t + 6], p[8 * t + 7]};
             i32x4 b0, b1, b2;
             split8(v, b0, b1, b2);
-            {
+            {       // the two d-halves are independent chains: interleave them
                 const i32x4 a0 = Vc[((t * 2 + 0) * 3 + 0) * 64], a1 = Vc[((t * 2 + 0) * 3 + 1) * 64], a2 = Vc[((t * 2 + 0) * 3 + 2) * 64];
-                PAX_6(a0, a1, a2, b0, b1, b2, O0);
-            }
-            {
-                const i32x4 a0 = Vc[((t * 2 + 1) * 3 + 0) * 64], a1 = Vc[((t * 2 + 1) * 3 + 1) * 64], a2 = Vc[((t * 2 + 1) * 3 + 2) * 64];
-                PAX_6(a0, a1, a2, b0, b1, b2, O1);
+                const i32x4 c0 = Vc[((t * 2 + 1) * 3 + 0) * 64], c1 = Vc[((t * 2 + 1) * 3 + 1) * 64], c2 = Vc[((t * 2 + 1) * 3 + 2) * 64];
+                PAX_MFMA(a2, b0, O0);      PAX_MFMA(c2, b0, O1);
+                PAX_MFMA(a1, b1, O0);      PAX_MFMA(c1, b1, O1);
+                PAX_MFMA(a0, b2, O0);      PAX_MFMA(c0, b2, O1);
+                PAX_MFMA(a1, b0, O0);      PAX_MFMA(c1, b0, O1);
+                PAX_MFMA(a0, b1, O0);      PAX_MFMA(c0, b1, O1);
+                PAX_MFMA(a0, b0, O0);      PAX_MFMA(c0, b0, O1);
             }
         }
         __syncthreads();                                   // done with stage kt & 1; the next tile is visible
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(256) void prefill_attention_x3_kernel(const float* 
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
                               int Tmax, bool x3, hipStream_t s) {
     const int qtiles = (T + 31) / 32;
-    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
+    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
     else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
 }
 
