@@ -1,3 +1,4 @@
+# usage: bash tools/ab_run.sh <variant> [<variant> ...]   (variants built by tools/ab_build.sh; "base" = the release library) -> decode ms per 63 steps at B = 32 and 64
 mkdir -p gpurun_out
 out=gpurun_out/ab3.txt
 : > $out

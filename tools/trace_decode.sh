@@ -1,4 +1,4 @@
-# usage: bash tools/r03_trace.sh <tag> [B] [extra env...]   -> gpurun_out/trace_<tag>.txt (per-kernel averages of the decode probe)
+# usage: bash tools/trace_decode.sh <tag> [B] [extra env...]   -> gpurun_out/trace_<tag>.txt (per-kernel averages of the decode probe)
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=$1; B=${2:-32}
