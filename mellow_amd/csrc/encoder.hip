@@ -245,9 +245,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // apart and took 2.3x the time of the plain kernel)
 __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restrict__ in, i32x4* __restrict__ out, int64_t M,
                                                           int C, const float* __restrict__ w, float eps) {
+    // The 32 rows of the workgroup are staged in LDS by pass 1 (coalesced row reads) and re-read from there by pass 2 in the
+    // (row % 32, k-half) order of an APB slot run: a second pass over global memory in that order touches 32 cache lines per load
+    // instruction (22 us per launch at M = 12448; from LDS: see profiles/).  Row stride C + 4 floats: the sixteen lanes of a
+    // ds_read_b128 group then sit on sixteen different bank quads.
+    extern __shared__ __attribute__((aligned(16))) float rows_s[];
     __shared__ float rs[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = C >> 2, KT = C >> 4;
+    const int nv = C >> 2, KT = C >> 4, RS = C + 4;
     const int64_t m0 = (int64_t)blockIdx.x * 32;
     // all eight rows of the wave are loaded before the first reduction (rows past M: a clamped re-read, result unused)
     float ss[8];
@@ -256,12 +261,14 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
         int64_t m = m0 + wave * 8 + i;
         m = m < M ? m : M - 1;
         const float4* src = reinterpret_cast<const float4*>(in + m * C);
+        float4* dst = reinterpret_cast<float4*>(rows_s + (wave * 8 + i) * RS);
         ss[i] = 0.f;
 #pragma unroll
         for (int q = 0; q < LN_MAXV; ++q) {
             const int v = lane + 64 * q;
             if (v < nv) {
                 const float4 x = src[v];
+                dst[v] = x;
                 ss[i] += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
             }
         }
@@ -272,13 +279,14 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
         if (lane == 0) rs[wave * 8 + i] = r;
     }
     __syncthreads();
-    const int64_t m = m0 + (lane & 31);
+    const int ml = lane & 31;
+    const int64_t m = m0 + ml;
     if (m >= M) return;
-    const float r = rs[lane & 31];
+    const float r = rs[ml];
     const int kh = lane >> 5;
     for (int kt = wave; kt < KT; kt += 4) {
         const int col = kt * 16 + kh * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(in + m * C + col), x1 = *reinterpret_cast<const float4*>(in + m * C + col + 4);
+        const float4 x0 = *reinterpret_cast<const float4*>(rows_s + ml * RS + col), x1 = *reinterpret_cast<const float4*>(rows_s + ml * RS + col + 4);
         const float4 w0 = *reinterpret_cast<const float4*>(w + col), w1 = *reinterpret_cast<const float4*>(w + col + 4);
         const float y[8] = {__fmul_rn(w0.x, __fmul_rn(x0.x, r)), __fmul_rn(w0.y, __fmul_rn(x0.y, r)), __fmul_rn(w0.z, __fmul_rn(x0.z, r)),
                             __fmul_rn(w0.w, __fmul_rn(x0.w, r)), __fmul_rn(w1.x, __fmul_rn(x1.x, r)), __fmul_rn(w1.y, __fmul_rn(x1.y, r)),
@@ -287,7 +295,13 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
     }
 }
 void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(rmsnorm_apb_kernel, dim3((M + 31) / 32), dim3(256), 0, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps);
+    const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 74 KB at C = 576: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rmsnorm_apb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rmsnorm_apb_kernel, dim3((M + 31) / 32), dim3(256), lds, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps);
 }
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, out, (int64_t)M, C, w, eps);

@@ -24,7 +24,7 @@ def gather_tokens(tokens: np.ndarray, lengths: np.ndarray, n_total: int, max_len
     Returns (tokens [n_total, max_len] padded with -1, lengths [n_total]) on every rank.
     ONE code path for every backend: `dist.all_gather` of equally sized int32 blocks into a list of tensors on `device`
     (cuda under "nccl" = RCCL over xGMI, cpu under gloo), so the line the 8-GPU run executes is the line the tests executed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         out = np.full((n_total, max_len), -1, dtype=np.int32)
         out[: tokens.shape[0], : tokens.shape[1]] = tokens
         return out, np.asarray(lengths, dtype=np.int32)

@@ -123,3 +123,35 @@ def test_bench_two_ranks_prints_one_line_with_n_gpus_2():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+
+
+_RCCL_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mellow_amd import dist as mdist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+toks = (np.arange(3 * 5, dtype=np.int32).reshape(3, 5) * 7) % 1000
+lens = np.asarray([5, 2, 4], dtype=np.int32)
+got, glens = mdist.gather_tokens(toks, lens, 3, 8, device=torch.device("cuda:0"))       # dist.all_gather of cuda blocks = RCCL
+assert got.shape == (3, 8) and np.array_equal(got[:, :5], toks) and (got[:, 5:] == -1).all() and glens.tolist() == lens.tolist()
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+"""
+
+
+def test_gather_runs_on_rccl_with_one_rank(tmp_path):
+    """The GPU box has one MI355X, so RCCL cannot be given two ranks -- but the gather's collective (`dist.all_gather` of device
+    blocks, the ONE code path of mellow_amd.dist.gather_tokens) can be executed on the "nccl" backend with a single rank: RCCL is
+    initialised, the blocks live on the GPU and the call the 8-GPU run makes is the call made here."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29747", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl ok" in r.stdout

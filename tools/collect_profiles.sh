@@ -19,13 +19,13 @@ python tools/pmc_mfma.py $O/pm/m_counter_collection.csv $O/pmc_gemm_mfma.json ||
 cp $O/pmc_gemm_traffic.json profiles/${R}_pmc_gemm_traffic.json     # bench.py prints `traffic` only from files whose source hash matches
 cp $O/pmc_decode_traffic.json profiles/${R}_pmc_decode_traffic.json
 # --- bench lines ---
-timeout 600 python bench.py --steps 5 --warmup 2 --inflight 2 > $O/bench.json 2> $O/bench.err
-timeout 300 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_f32.json 2>/dev/null
+timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+timeout 300 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_f32.json 2>/dev/null
 timeout 300 python bench.py --steps 5 --warmup 2 --precision fp8 --no-cpu-baseline > $O/bench_fp8.json 2>/dev/null
-timeout 300 python bench.py --steps 3 --warmup 1 --preset configs2 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_configs2.json 2>/dev/null
-timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_configs4.json 2>/dev/null
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs2 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_configs2.json 2>/dev/null
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_configs4.json 2>/dev/null
 # --- kernel trace + stats of the default command, decode timeline ---
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 > $O/bench_under_rocprofv3.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_under_rocprofv3.json 2>/dev/null
 cp $O/stats/st_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || find $O/stats -name "*stats*.csv" | head
 timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
 python tools/trace_summary.py $O/trace_dec/tr_kernel_trace.csv 40 > $O/decode_step_timeline.txt 2>&1
