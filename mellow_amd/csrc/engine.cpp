@@ -468,8 +468,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->step_exec) hipGraphExecDestroy(e->step_exec);
     if (e->step_exec8) hipGraphExecDestroy(e->step_exec8);
-    if (e->owns_weights)
-        for (void* p : e->allocs) hipFree(p);
+    for (void* p : e->allocs) hipFree(p);      // a fork's list holds only what it allocated itself (resample banks): the weights are its parent's
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
                                   &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->lm_xn3, &e->lm_o3, &e->lm_h3, &e->kcache, &e->vcache, &e->dec,
