@@ -779,7 +779,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     }
     // scratch for the load-time weight composition of dec_qkv2_kernel (fp32 decode weights only)
     float *cmpF = nullptr, *cmpD = nullptr, *cmpQ = nullptr, *cmpCat = nullptr;
-    static const bool no_fuse = getenv("MELLOW_DECODE_FUSE") && getenv("MELLOW_DECODE_FUSE")[0] == '0';   // keep the 5-launch layer
+    const bool no_fuse = getenv("MELLOW_DECODE_FUSE") && getenv("MELLOW_DECODE_FUSE")[0] == '0';   // keep the 5-launch layer (read per engine)
     const bool fuse = !e->fp8_decode && !no_fuse && H == 576 && I == 1536;
     if (fuse) {
         HIPCHK(hipMalloc(&cmpF, (size_t)960 * 576 * 4));

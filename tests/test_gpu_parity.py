@@ -720,6 +720,53 @@ def test_config4_shape_30s_clips_max_len_128(engine, synth_sd):
     assert np.array_equal(t[0, :4], np.asarray(want)[0])
 
 
+def test_fused_and_five_launch_decode_layers_agree(engine_f32, synth_sd, monkeypatch, golden_dir):
+    """The decode layer runs as 4 launches (the down projection of a layer and the q/k/v projection of the next one in one kernel,
+    on the weight W'Wd composed at load time) or, with MELLOW_DECODE_FUSE=0, as the 5 launches of round 2.  Both must give the
+    reference's tokens (the fused form is what every other test exercises); their last-position logits differ only by fp32
+    summation-order noise.  B = 2 for 40 steps, and B = 33 (two row blocks, the second with one row)."""
+    from mellow_amd.engine import Engine
+    monkeypatch.setenv("MELLOW_DECODE_FUSE", "0")
+    e5 = Engine(device=0)
+    e5.load_state_dict(synth_sd)
+    monkeypatch.delenv("MELLOW_DECODE_FUSE")
+    try:
+        g = np.load(os.path.join(golden_dir, "late.npz"))
+        a1, a2, ids = synth.make_batch(2)
+        t5, *_ = e5.generate(a1, a2, ids, max_len=40, stop_id=0, ignore_stop=True)
+        t4, *_ = engine_f32.generate(a1, a2, ids, max_len=40, stop_id=0, ignore_stop=True)
+        assert np.array_equal(t5, g["tokens"][:, :40]) and np.array_equal(t4, t5)
+        prefix = engine_f32.prefix(a1, a2, ids)
+        l4 = engine_f32.lm_prefill(prefix, reserve=4)
+        l5 = e5.lm_prefill(prefix, reserve=4)
+        for step in range(3):
+            _close(l4, l5, rel=0, atol=1e-3, name=f"fused vs five-launch logits, step {step}")
+            tok = l5.argmax(-1).to(torch.int32)
+            l4, l5 = engine_f32.lm_decode_step(tok), e5.lm_decode_step(tok)
+        b1, b2, bi = synth.make_batch(33)
+        u5, *_ = e5.generate(b1, b2, bi, max_len=6, stop_id=0, ignore_stop=True)
+        u4, *_ = engine_f32.generate(b1, b2, bi, max_len=6, stop_id=0, ignore_stop=True)
+        assert np.array_equal(u4, u5)
+    finally:
+        e5.close()
+
+
+def test_fork_needs_a_loaded_engine_and_shares_its_answers(engine_f32):
+    from mellow_amd.engine import Engine, EngineError
+    raw = Engine(device=0)
+    with pytest.raises(EngineError, match="fork needs"):
+        raw.fork()
+    raw.close()
+    child = engine_f32.fork()
+    a1, a2, ids = synth.make_batch(2)
+    want, *_ = engine_f32.generate(a1, a2, ids, max_len=5, stop_id=0, ignore_stop=True)
+    got, *_ = child.generate(a1, a2, ids, max_len=5, stop_id=0, ignore_stop=True)
+    assert np.array_equal(got, want)
+    child.close()
+    again, *_ = engine_f32.generate(a1, a2, ids, max_len=5, stop_id=0, ignore_stop=True)      # the parent outlives its fork
+    assert np.array_equal(again, want)
+
+
 def test_pipelined_contexts_give_identical_tokens(engine_f32, synth_sd):
     """mellow_amd.serve.EnginePool: three contexts on one GPU sharing one weight copy, batches in flight concurrently == one engine,
     batch by batch."""
