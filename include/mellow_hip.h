@@ -169,6 +169,10 @@ int  mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, 
                            int iters, float* ms2);
 int  mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C,
                            int iters, float* ms2);
+/* The decode step's lm_head kernel on caller-supplied rows (dev): logits[B][vocab] = x[B][hidden] . lm_head^T with the engine's
+ * own head weights (the e4m3 copy in MELLOW_PRECISION_FP8; act_fp8 != 0 then also quantises x inside the kernel: one scale per
+ * batch row and 72-column slice, fp8 matrix pipe).  Invalidates the decode state of an earlier prefill. */
+int  mellow_debug_dec_head(mellow_engine_t* e, const float* x, int B, int act_fp8, float* logits);
 
 /* ---- measurement ---------------------------------------------------------------------------------
  * Per-kernel-family accounting with HIP events on the engine's stream.  When enabled, every launch
@@ -201,8 +205,9 @@ int         mellow_set_graph(mellow_engine_t* e, int on);
  *      mellow_engine_load_tensor.  The reference has no counterpart (fp32 ATen matmuls throughout).
  *   MELLOW_PRECISION_F32 (default): exact fp32 on v_mfma_f32_32x32x2_f32 -- the mode every parity claim refers to.
  *   MELLOW_PRECISION_FP8: BASELINE config 5 -- OCP e4m3 weights (per-output-channel scale) and activations (per-row
- *     scale, quantised on the fly), fp32 accumulate on v_mfma_f32_32x32x16_fp8_fp8.  Front-end (STFT, mel), K % 64 != 0
- *     layers and the decode step stay fp32.  Not bit-exact: report token agreement.
+ *     scale, quantised on the fly), fp32 accumulate on v_mfma_f32_32x32x16_fp8_fp8; the GEMM kernels of the decode step read
+ *     e4m3 weights and quantise their activations in registers (one scale per batch row and wave k-slice).  Front-end (STFT,
+ *     mel), K % 64 != 0 layers, the attentions and the norms stay fp32.  Not bit-exact: report token agreement.
  *   MELLOW_PRECISION_F32X3 (experimental): fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into
  *     three bf16 terms, the six largest partial products (the rest is < 2^-23 |a*b|) are accumulated in fp32:
  *     fp32-accurate (error against fp64 measured <= the fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32. */

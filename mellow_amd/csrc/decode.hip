@@ -70,6 +70,43 @@ __device__ __forceinline__ float4 ldw(const float* __restrict__ Wp, int64_t slot
         return ldg_nt(reinterpret_cast<const float4*>(Wp) + slot);
     }
 }
+// W8 == 2 ("A8"): the e4m3 words go to the fp8 matrix pipe as they are (v_mfma_f32_32x32x16_fp8_fp8 / 16x16x32) and the
+// ACTIVATIONS are quantised to e4m3 in the consumer's registers, right after the fp32 fragments have landed: one scale per
+// (batch row, k-slice of the wave) = amax / 448 of the values the wave holds for that row, applied to the wave's accumulators
+// before the cross-wave reduction -- finer than a per-row scale and free of any cross-workgroup statistic.  No repacking: a
+// lane's e4m3 word of k-tile t and of k-tile t+1 form the 8-byte A operand, and the activation fragments of the same two
+// tiles (same lane -> same k positions) the B operand; the contraction only needs A and B to agree on which k a byte holds.
+__device__ __forceinline__ uint32_t ldw8(const float* __restrict__ Wp, int64_t slot) {
+    return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Wp) + slot);
+}
+__device__ __forceinline__ float f4amax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ uint32_t q4_e4m3(float4 v, float inv) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * inv, v.y * inv, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * inv, v.w * inv, w, true);
+    return (uint32_t)w;
+}
+__device__ __forceinline__ long pk64(uint32_t lo, uint32_t hi) { return (long)(((uint64_t)hi << 32) | (uint64_t)lo); }
+// N k-tiles of a wave on the fp8 pipe, two tiles per instruction (an odd last tile is paired with zeros)
+template <int N>
+__device__ __forceinline__ f32x16 mfma8_32(f32x16 acc, const uint32_t (&w)[N], const uint32_t (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pk64(w[i], i + 1 < N ? w[i + 1] : 0u), pk64(x[i], i + 1 < N ? x[i + 1] : 0u), acc, 0, 0, 0);
+    return acc;
+}
+template <int N>
+__device__ __forceinline__ f32x4 mfma8_16(f32x4 acc, const uint32_t (&w)[N], const uint32_t (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk64(w[i], i + 1 < N ? w[i + 1] : 0u), pk64(x[i], i + 1 < N ? x[i + 1] : 0u), acc, 0, 0, 0);
+    return acc;
+}
+// (amax of a row's slice) -> (1 / scale, scale); an all-zero slice quantises to zeros
+__device__ __forceinline__ void a8_scales(float amax, float& inv, float& sc) {
+    inv = amax > 0.f ? 448.0f / amax : 0.f;
+    sc = amax * (1.0f / 448.0f);
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -94,7 +131,7 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 #endif
 constexpr int QW = MELLOW_QKV_WAVES;                 // compute waves: 3 x 3 k-tiles or 9 x 1
 constexpr int QKV_THREADS = QW * 64 < 256 ? 256 : QW * 64;
-template <int KCD, bool BLK, bool FIRST, bool W8>
+template <int KCD, bool BLK, bool FIRST, int W8>      // W8: 0 fp32 weights, 1 e4m3 weights widened, 2 e4m3 weights and activations (fp8 MFMA)
 __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                               const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[QW * 16 * 64];
@@ -119,9 +156,11 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
         const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
+        uint32_t w8[KPW];
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-            w[i] = ldw<W8>(Wp, wslot + i * 64);
+            if constexpr (W8 == 2) w8[i] = ldw8(Wp, wslot + i * 64);
+            else w[i] = ldw<W8 != 0>(Wp, wslot + i * 64);
             x[i] = xb[i * 64];
 #pragma unroll
             for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
@@ -136,13 +175,26 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
             float4 xv = x[i];
 #pragma unroll
             for (int s = 0; s < KCD; ++s) xv = f4add(xv, sl[i][s]);
-            acc = mfma4(acc, w[i], xv);
+            if constexpr (W8 == 2) x[i] = xv;            // quantised below, once the wave's slice of the row is known
+            else acc = mfma4(acc, w[i], xv);
             // side jobs of two n-tiles (the workgroups of one k-chunk see every row of x_new on these 72 columns):
             //   nt == 0: partial sum of squares per row (the attention's RMS statistic)
             //   nt == 1: x_new row-major (the o_proj's residual operand)
             if (nt == 0) ssp += f4ssq(xv);
             if (nt == 1)
                 *reinterpret_cast<float4*>(a.xnewR + ((int64_t)rb * 32 + (lane & 31)) * 576 + (k8_0 + i) * 8 + (lane >> 5) * 4) = xv;
+        }
+        if constexpr (W8 == 2) {
+            float am = 0.f, inv, sc;
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) am = fmaxf(am, f4amax(x[i]));
+            a8_scales(half_max(am), inv, sc);
+            uint32_t xq[KPW];
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) xq[i] = q4_e4m3(x[i], inv);
+            acc = mfma8_32<KPW>(acc, w8, xq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= sc;
         }
         if (nt == 0) {
             ssp = half_sum(ssp);                 // the two k-halves of a row sit in lanes m and m + 32
@@ -535,7 +587,7 @@ constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
 // bytes one CU has to ingest)
 // Chosen per launch: 8 rows for a single row block (B <= 32: 52.8 -> 52.2 ms of decode per 63 steps), 16 rows otherwise (at
 // B = 64 the 288 eight-row workgroups no longer fit the 256 CUs: 76.3 -> 78.5 ms).  MELLOW_OPROJ_ROWS forces one form.
-template <bool BLK, bool W8, int OP_ROWS>
+template <bool BLK, int W8, int OP_ROWS>
 __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16,
                                                                   const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
@@ -556,13 +608,19 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
     if (erow_ok) xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
 
     float4 w[TPW], os[TPW][DEC_TS];
+    uint32_t w8[TPW];
     float ms[TPW][DEC_TS], ls[TPW][DEC_TS];
     const int64_t row = (int64_t)rb * 32 + mh * 16 + ml;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = wave + OP_WAVES * i, tc = t < K16 ? t : K16 - 1;     // clamped: out-of-range tiles get zero weights
-        w[i] = ldw<W8>(Wp16, wslot + (int64_t)tc * 64);
-        if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (W8 == 2) {
+            w8[i] = ldw8(Wp16, wslot + (int64_t)tc * 64);
+            if (t >= K16) w8[i] = 0u;
+        } else {
+            w[i] = ldw<W8 != 0>(Wp16, wslot + (int64_t)tc * 64);
+            if (t >= K16) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
         for (int s = 0; s < DEC_TS; ++s) {
@@ -597,10 +655,28 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
             O.x += os[i][s].x * f; O.y += os[i][s].y * f; O.z += os[i][s].z * f; O.w += os[i][s].w * f;
         }
         const float inv = 1.0f / L;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, O.x * inv, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, O.y * inv, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, O.z * inv, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, O.w * inv, acc, 0, 0, 0);
+        if constexpr (W8 == 2) {
+            os[i][0] = make_float4(O.x * inv, O.y * inv, O.z * inv, O.w * inv);      // the merged activation, quantised below
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, O.x * inv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, O.y * inv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, O.z * inv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, O.w * inv, acc, 0, 0, 0);
+        }
+    }
+    if constexpr (W8 == 2) {
+        // a batch row's values of this wave's k-tiles sit in the four lanes ml + 16 q
+        float am = 0.f, inv, sc;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) am = fmaxf(am, f4amax(os[i][0]));
+        am = fmaxf(am, swz_xor16(am));
+        a8_scales(half_max(am), inv, sc);
+        uint32_t xq[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) xq[i] = q4_e4m3(os[i][0], inv);
+        acc = mfma8_16<TPW>(acc, w8, xq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= sc;
     }
     // D[i = n_local = 4*(lane>>4) + r][j = m_local = lane&15]
 #pragma unroll
@@ -639,7 +715,7 @@ enum { OUT_LOGITS = 1 };
 #define MELLOW_LM_WAVES 8     // 8 x 9 k-tiles: 53.45 vs 54.35 ms of decode per 63 steps with 4 x 18 (6 / 9 / 12 waves: 54.1 / 54.1 / 53.7)
 #endif
 constexpr int LM_WAVES = MELLOW_LM_WAVES;
-template <int OUT, bool BLK, bool W8>
+template <int OUT, bool BLK, int W8>
 __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                         const float* __restrict__ XF, int N, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[LM_WAVES * 16 * 64];
@@ -651,18 +727,36 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs 
     const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
     const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
     float4 w[KPW], x[KPW];
+    uint32_t w8[KPW];
     const bool dbg = tid == 0 && nt == 0 && rb == 0;
     const int dslot = 5;
     kstamp(dslot, 0, dbg);
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) { w[i] = ldw<W8>(Wp, wslot + i * 64); x[i] = xp[i * 64]; }
+    for (int i = 0; i < KPW; ++i) {
+        if constexpr (W8 == 2) w8[i] = ldw8(Wp, wslot + i * 64);
+        else w[i] = ldw<W8 != 0>(Wp, wslot + i * 64);
+        x[i] = xp[i * 64];
+    }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(dslot, 1, dbg);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (W8 == 2) {
+        float am = 0.f, inv, sc;
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], x[i]);
+        for (int i = 0; i < KPW; ++i) am = fmaxf(am, f4amax(x[i]));
+        a8_scales(half_max(am), inv, sc);
+        uint32_t xq[KPW];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) xq[i] = q4_e4m3(x[i], inv);
+        acc = mfma8_32<KPW>(acc, w8, xq);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= sc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], x[i]);
+    }
     kstamp(dslot, 2, dbg && acc[0] == acc[0]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
@@ -726,7 +820,7 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs 
 #define MELLOW_GU_WAVES 4
 #endif
 constexpr int GU_WAVES = MELLOW_GU_WAVES;
-template <bool BLK, bool W8>
+template <bool BLK, int W8>
 __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16,
                                                                      const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[GU_WAVES * 8 * 64];
@@ -741,9 +835,11 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
     // epilogue thread (m = tid>>1, q = tid&1), tid < 64: its row's 36 sum-of-squares partials, issued up front
     const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + ((tid >> 1) & 31)) * 40);
     float4 w[TPW], x0[TPW], x1[TPW], s4[9];
+    uint32_t w8[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        w[i] = ldw<W8>(Wp16, wslot + i * 64);
+        if constexpr (W8 == 2) w8[i] = ldw8(Wp16, wslot + i * 64);
+        else w[i] = ldw<W8 != 0>(Wp16, wslot + i * 64);
         x0[i] = xp[(i * 2) * 64];
         x1[i] = xp[(i * 2 + 1) * 64];
     }
@@ -753,6 +849,22 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (W8 == 2) {
+        // rows 0..15 (x0) and 16..31 (x1): a row's values of this wave's k-tiles sit in the four lanes (m % 16) + 16 q
+        float am0 = 0.f, am1 = 0.f, inv0, sc0, inv1, sc1;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { am0 = fmaxf(am0, f4amax(x0[i])); am1 = fmaxf(am1, f4amax(x1[i])); }
+        am0 = fmaxf(am0, swz_xor16(am0)); am1 = fmaxf(am1, swz_xor16(am1));
+        a8_scales(half_max(am0), inv0, sc0);
+        a8_scales(half_max(am1), inv1, sc1);
+        uint32_t q0[TPW], q1[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { q0[i] = q4_e4m3(x0[i], inv0); q1[i] = q4_e4m3(x1[i], inv1); }
+        acc0 = mfma8_16<TPW>(acc0, w8, q0);
+        acc1 = mfma8_16<TPW>(acc1, w8, q1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] *= sc0; acc1[r] *= sc1; }
+    } else {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x0[i].x, acc0, 0, 0, 0);
@@ -763,6 +875,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x1[i].z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x0[i].w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x1[i].w, acc1, 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -808,7 +921,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
 // 53.0-53.2 with 6 x 4, 8 x 3 or 12 x 2 (same box, tools/ab_build.sh)
 constexpr int DN_WAVES = MELLOW_DOWN_WAVES;
 static_assert(DN_WAVES >= 4 && 192 % (8 * DN_WAVES) == 0, "the epilogue needs 256 threads; waves must divide the k-tiles");
-template <bool BLK, bool W8>
+template <bool BLK, int W8>
 __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
                                                                  const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
@@ -822,9 +935,11 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
     const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
     kstamp(4, 0, dbg);
     float4 w[KPW], h4[KPW];
+    uint32_t w8[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        w[i] = ldw<W8>(Wp, wslot + i * 64);
+        if constexpr (W8 == 2) w8[i] = ldw8(Wp, wslot + i * 64);
+        else w[i] = ldw<W8 != 0>(Wp, wslot + i * 64);
         h4[i] = hp[i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -832,8 +947,21 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    if constexpr (W8 == 2) {
+        float am = 0.f, inv, sc;
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], h4[i]);
+        for (int i = 0; i < KPW; ++i) am = fmaxf(am, f4amax(h4[i]));
+        a8_scales(half_max(am), inv, sc);
+        uint32_t xq[KPW];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) xq[i] = q4_e4m3(h4[i], inv);
+        acc = mfma8_32<KPW>(acc, w8, xq);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] *= sc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) acc = mfma4(acc, w[i], h4[i]);
+    }
     kstamp(4, 2, dbg && acc[0] == acc[0]);
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[q];
@@ -872,9 +1000,15 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
 //     Consumer: dec_attn_kernel<FUSED> sums the Q2_NPQ pq slabs and forms x_new = x_mid + sum of the Q2_HC down slabs.
 // ----------------------------------------------------------------------------------------------------
 // Q2W = waves per workgroup (chosen per launch: 4 for one row block, Q2W otherwise)
-template <bool BLK, int Q2W>
-__global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wq2,
-                                                                  const float* __restrict__ Wd) {
+// Operands: Wx = W' (P-layout, K8x k-tiles per n-tile), Wh = W' Wd (K8h k-tiles per n-tile), Wd = the down weight (192 k-tiles).
+//   fp32 (W8 == 0): Wx and Wh are the two column ranges of ONE matrix [30][72 + 192] (K8x = K8h = Q2_K8)
+//   e4m3 (W8 != 0): three separately quantised matrices (the q/k/v copy of the unfused layer, the composed one, the down copy),
+//                   one scale per packed row each: sc_x, sc_h, sc_d; W8 == 2 also quantises x_mid / h per wave slice (see ldw8)
+template <bool BLK, int Q2W, int W8>
+__global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wx, int K8x,
+                                                            const float* __restrict__ Wh, int K8h, const float* __restrict__ Wd,
+                                                            const float* __restrict__ sc_x, const float* __restrict__ sc_h,
+                                                            const float* __restrict__ sc_d) {
     __shared__ __attribute__((aligned(16))) float red[Q2W * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, rb = blockIdx.y;
@@ -888,33 +1022,71 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, con
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     int nt, slab;
     bool side = false;
+    const float* wsc = sc_x;
     if (b < 60) {              // x part (workgroup-uniform branch; each side keeps its loads straight-line)
         nt = b % 30; slab = b / 30;
         const int k8_0 = slab * 36 + wave * XT;
-        const int64_t wslot = ((int64_t)nt * Q2_K8 + k8_0) * 64 + lane;
+        const int64_t wslot = ((int64_t)nt * K8x + k8_0) * 64 + lane;
         const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         float4 w[XT], x[XT];
+        uint32_t w8[XT];
 #pragma unroll
-        for (int i = 0; i < XT; ++i) { w[i] = ldg_nt(reinterpret_cast<const float4*>(Wq2) + wslot + i * 64); x[i] = xb[i * 64]; }
+        for (int i = 0; i < XT; ++i) {
+            if constexpr (W8 == 2) w8[i] = ldw8(Wx, wslot + i * 64);
+            else w[i] = ldw<W8 != 0>(Wx, wslot + i * 64);
+            x[i] = xb[i * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (W8 == 2) {
+            float am = 0.f, inv, sc;
 #pragma unroll
-        for (int i = 0; i < XT; ++i) acc = mfma4(acc, w[i], x[i]);
+            for (int i = 0; i < XT; ++i) am = fmaxf(am, f4amax(x[i]));
+            a8_scales(half_max(am), inv, sc);
+            uint32_t xq[XT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i) xq[i] = q4_e4m3(x[i], inv);
+            acc = mfma8_32<XT>(acc, w8, xq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= sc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) acc = mfma4(acc, w[i], x[i]);
+        }
     } else {                   // h part
         const int idx = b - 60, hc = idx / 48;
         nt = idx % 48;
         side = nt >= 30;
         slab = side ? hc : 2 + hc;
+        wsc = side ? sc_d : sc_h;
         const int k8_0 = hc * (192 / Q2_HC) + wave * HT;
-        const float4* wp = side ? reinterpret_cast<const float4*>(Wd) + ((int64_t)(nt - 30) * 192 + k8_0) * 64 + lane
-                                : reinterpret_cast<const float4*>(Wq2) + ((int64_t)nt * Q2_K8 + 72 + k8_0) * 64 + lane;
+        const float* wbase = side ? Wd : Wh;
+        const int64_t wslot = side ? ((int64_t)(nt - 30) * 192 + k8_0) * 64 + lane : ((int64_t)nt * K8h + k8_0) * 64 + lane;
         const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
         float4 w[HT], h4[HT];
+        uint32_t w8[HT];
 #pragma unroll
-        for (int i = 0; i < HT; ++i) { w[i] = ldg_nt(wp + i * 64); h4[i] = hp[i * 64]; }
+        for (int i = 0; i < HT; ++i) {
+            if constexpr (W8 == 2) w8[i] = ldw8(wbase, wslot + i * 64);
+            else w[i] = ldw<W8 != 0>(wbase, wslot + i * 64);
+            h4[i] = hp[i * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         kstamp(7, 1, dbg);
+        if constexpr (W8 == 2) {
+            float am = 0.f, inv, sc;
 #pragma unroll
-        for (int i = 0; i < HT; ++i) acc = mfma4(acc, w[i], h4[i]);
+            for (int i = 0; i < HT; ++i) am = fmaxf(am, f4amax(h4[i]));
+            a8_scales(half_max(am), inv, sc);
+            uint32_t xq[HT];
+#pragma unroll
+            for (int i = 0; i < HT; ++i) xq[i] = q4_e4m3(h4[i], inv);
+            acc = mfma8_32<HT>(acc, w8, xq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= sc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < HT; ++i) acc = mfma4(acc, w[i], h4[i]);
+        }
         kstamp(7, 2, dbg && acc[0] == acc[0]);
         if (side) nt -= 30;
     }
@@ -934,6 +1106,10 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, con
             v[j] = sacc;
         }
         const int n = nt * 32 + 8 * gq + 4 * hh;
+        if (W8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= wsc[n + j];
+        }
         const float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (side) reinterpret_cast<float4*>(a.dslabF)[(int64_t)slab * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
         else *reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n) = o;
@@ -1132,22 +1308,30 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
         if (a.blk_live) hipLaunchKernelGGL((KERNEL<true>), GRID, BLOCK, 0, s, __VA_ARGS__);                       \
         else hipLaunchKernelGGL((KERNEL<false>), GRID, BLOCK, 0, s, __VA_ARGS__);                                 \
     } while (0)
+// weight mode of a launch: 0 fp32, 1 e4m3 weights widened to fp32, 2 e4m3 weights and activations on the fp8 matrix pipe (a.a8)
+static inline int w8_mode(const DecArgs& a, const float* wscale) { return wscale ? (a.a8 ? 2 : 1) : 0; }
 #define MELLOW_LAUNCH_BLK_W8(KERNEL, GRID, BLOCK, ...)                                                            \
     do {                                                                                                         \
-        if (a.blk_live && wscale) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);     \
-        else if (a.blk_live) hipLaunchKernelGGL((KERNEL<true, false>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);          \
-        else if (wscale) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);              \
-        else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);                         \
+        const int mode_ = w8_mode(a, wscale);                                                                    \
+        if (a.blk_live && mode_ == 2) hipLaunchKernelGGL((KERNEL<true, 2>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);    \
+        else if (a.blk_live && mode_ == 1) hipLaunchKernelGGL((KERNEL<true, 1>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale); \
+        else if (a.blk_live) hipLaunchKernelGGL((KERNEL<true, 0>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);              \
+        else if (mode_ == 2) hipLaunchKernelGGL((KERNEL<false, 2>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);             \
+        else if (mode_ == 1) hipLaunchKernelGGL((KERNEL<false, 1>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);             \
+        else hipLaunchKernelGGL((KERNEL<false, 0>), GRID, BLOCK, 0, s, __VA_ARGS__, wscale);                             \
     } while (0)
 void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStream_t s, const float* wscale) {
     const dim3 grid(30, DEC_KC_QKV, a.RB);
     // the first qkv launch of a step (a.first) always starts from a materialised x (kcd == 0); later ones sum the down slabs
 #define MELLOW_QKV(KCD, FIRST)                                                                              \
     do {                                                                                                    \
-        if (a.blk_live && wscale) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, true>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
-        else if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, false>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);        \
-        else if (wscale) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, true>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
-        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, false>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);                       \
+        const int mode_ = w8_mode(a, wscale);                                                                \
+        if (a.blk_live && mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
+        else if (a.blk_live && mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
+        else if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);        \
+        else if (mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
+        else if (mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
+        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);                       \
     } while (0)
     if (kcd == 0 && a.first) MELLOW_QKV(0, true);
     else if (kcd == 0) MELLOW_QKV(0, false);
@@ -1166,22 +1350,43 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
     else if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true, false>), grid, block, 0, s, a, k_cache, v_cache);
     else hipLaunchKernelGGL((dec_attn_kernel<false, false, false>), grid, block, 0, s, a, k_cache, v_cache);
 }
-void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
+// fp32 form: Wq2 = [30][Q2_K8] (W' | W' Wd);  e4m3 form (sc_x != null): three separately quantised matrices (kernel comment)
+static void launch_dec_qkv2_any(const DecArgs& a, const float* Wx, int K8x, const float* Wh, int K8h, const float* Wd,
+                                const float* sc_x, const float* sc_h, const float* sc_d, hipStream_t s) {
     // waves per workgroup: 4 x (9 | 12) k-tiles when there is one row block (a 4-way instead of a 12-way LDS reduction: 49.55 vs
     // 49.98 ms of decode per 63 steps at B = 32), 12 x (3 | 4) otherwise (B = 64: 76.3 vs 77.2 ms); -DMELLOW_Q2_WAVES=n forces one
     const dim3 grid(Q2_BLOCKS, a.RB);
 #ifdef MELLOW_Q2_WAVES_FORCED
-    const bool few = false;
+    bool few = false;
 #else
-    const bool few = a.RB == 1;
+    bool few = a.RB == 1;
 #endif
+    const int mode = w8_mode(a, sc_x);
+    // (activations on the fp8 pipe: a wave's k-slice is the unit of the activation scale, so the wave count must not depend on
+    //  the batch size -- a row's tokens would otherwise change with the number of row blocks around it)
+    if (mode == 2) few = false;
+#define MELLOW_Q2(BLKV, WV, MODE) \
+    hipLaunchKernelGGL((dec_qkv2_kernel<BLKV, WV, MODE>), grid, dim3(WV * 64), 0, s, a, Wx, K8x, Wh, K8h, Wd, sc_x, sc_h, sc_d)
+#define MELLOW_Q2_MODES(BLKV, WV)                  \
+    do {                                           \
+        if (mode == 2) MELLOW_Q2(BLKV, WV, 2);     \
+        else if (mode == 1) MELLOW_Q2(BLKV, WV, 1);\
+        else MELLOW_Q2(BLKV, WV, 0);               \
+    } while (0)
     if (few) {
-        if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true, 4>), grid, dim3(256), 0, s, a, Wq2, Wd);
-        else hipLaunchKernelGGL((dec_qkv2_kernel<false, 4>), grid, dim3(256), 0, s, a, Wq2, Wd);
+        if (a.blk_live) MELLOW_Q2_MODES(true, 4); else MELLOW_Q2_MODES(false, 4);
     } else {
-        if (a.blk_live) hipLaunchKernelGGL((dec_qkv2_kernel<true, Q2_WAVES>), grid, dim3(Q2_WAVES * 64), 0, s, a, Wq2, Wd);
-        else hipLaunchKernelGGL((dec_qkv2_kernel<false, Q2_WAVES>), grid, dim3(Q2_WAVES * 64), 0, s, a, Wq2, Wd);
+        if (a.blk_live) MELLOW_Q2_MODES(true, Q2_WAVES); else MELLOW_Q2_MODES(false, Q2_WAVES);
     }
+#undef MELLOW_Q2_MODES
+#undef MELLOW_Q2
+}
+void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
+    launch_dec_qkv2_any(a, Wq2, Q2_K8, Wq2 + (size_t)72 * 64 * 4, Q2_K8, Wd, nullptr, nullptr, nullptr, s);
+}
+void launch_dec_qkv2_w8(const DecArgs& a, const float* Wx8, const float* sc_x, const float* Wh8, const float* sc_h,
+                        const float* Wd8, const float* sc_d, hipStream_t s) {
+    launch_dec_qkv2_any(a, Wx8, 72, Wh8, 192, Wd8, sc_x, sc_h, sc_d, s);
 }
 // C[M][N] (fp32) = A[M][K] . B[K][N] with fp64 products and accumulation, rounded once: the load-time composition of two
 // weight matrices (W_qkv' . W_down) for dec_qkv2_kernel.  16 x 16 outputs per workgroup, operands staged through LDS.
@@ -1216,10 +1421,13 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const 
         if (rows == 8) hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 8>), dim3(36, 4 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);  \
         else hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 16>), dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);           \
     } while (0)
-    if (a.blk_live && wscale) MELLOW_OPROJ(true, true);
-    else if (a.blk_live) MELLOW_OPROJ(true, false);
-    else if (wscale) MELLOW_OPROJ(false, true);
-    else MELLOW_OPROJ(false, false);
+    const int mode = w8_mode(a, wscale);
+    if (a.blk_live && mode == 2) MELLOW_OPROJ(true, 2);
+    else if (a.blk_live && mode == 1) MELLOW_OPROJ(true, 1);
+    else if (a.blk_live) MELLOW_OPROJ(true, 0);
+    else if (mode == 2) MELLOW_OPROJ(false, 2);
+    else if (mode == 1) MELLOW_OPROJ(false, 1);
+    else MELLOW_OPROJ(false, 0);
 #undef MELLOW_OPROJ
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
@@ -1239,10 +1447,13 @@ void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipSt
 }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale) {
     const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
-    if (a.blk_live && wscale) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, true>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, false>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (wscale) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, true>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, false>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    const int mode = w8_mode(a, wscale);
+    if (a.blk_live && mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 2>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (a.blk_live && mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 1>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 0>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 2>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else if (mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 1>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 0>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
 }
 // fp32 packed decode weight (P-layout: 32 rows per tile, or P16: 16 rows per tile; `slots` float4 slots per tile) -> one
 // 4-byte word of four e4m3 values per slot + one scale per packed row (amax / 448): one workgroup per tile

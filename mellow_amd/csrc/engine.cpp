@@ -102,6 +102,7 @@ struct LMLayerW {
     // decode, layers >= 1: [W'_l | W'_l Wd_{l-1}] (960 x (576 + 1536), P-layout, the product formed in fp64 at load time): the
     // operand of dec_qkv2_kernel, which runs the down projection of layer l-1 and the q/k/v projection of layer l as one launch
     float* qkv2 = nullptr;
+    float *q2h8 = nullptr, *q2h_sc = nullptr;    // fp8 mode: the composed part W'_l . Wd_{l-1} alone, e4m3 + one scale per packed row
     // fp8 mode: e4m3 copies of the four decode operands in the same slot order (one 4-byte word per float4 slot) and one
     // scale per packed weight row (launch_pack_dec_fp8)
     float *qkv8 = nullptr, *qkv_sc = nullptr, *o8 = nullptr, *o_sc = nullptr, *gu8 = nullptr, *gu_sc = nullptr, *dn8 = nullptr,
@@ -189,6 +190,7 @@ struct mellow_engine {
     // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
     bool fp8 = false;
     bool fp8_decode = false;                     // fp8 mode: the decode kernels read e4m3 weights too (off: MELLOW_FP8_DECODE=0)
+    bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (off: MELLOW_FP8_DECODE_ACT=0)
     bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (off: MELLOW_FP8_PREFILL=0, a test isolating the decode weights)
     float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
     int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
@@ -780,12 +782,12 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     // scratch for the load-time weight composition of dec_qkv2_kernel (fp32 decode weights only)
     float *cmpF = nullptr, *cmpD = nullptr, *cmpQ = nullptr, *cmpCat = nullptr;
     const bool no_fuse = getenv("MELLOW_DECODE_FUSE") && getenv("MELLOW_DECODE_FUSE")[0] == '0';   // keep the 5-launch layer (read per engine)
-    const bool fuse = !e->fp8_decode && !no_fuse && H == 576 && I == 1536;
+    const bool fuse = !no_fuse && H == 576 && I == 1536;
     if (fuse) {
         HIPCHK(hipMalloc(&cmpF, (size_t)960 * 576 * 4));
         HIPCHK(hipMalloc(&cmpD, (size_t)576 * 1536 * 4));
         HIPCHK(hipMalloc(&cmpQ, (size_t)960 * 1536 * 4));
-        HIPCHK(hipMalloc(&cmpCat, (size_t)960 * 2112 * 4));
+        HIPCHK(hipMalloc(&cmpCat, (size_t)1024 * 2112 * 4));     // fp32: [W' | Q] row-major; fp8 mode: Q alone in P-layout (1024 x 1536)
     }
     for (int l = 0; l < e->cfg.num_layers; ++l) {
         const std::string p = L + "model.layers." + std::to_string(l) + ".";
@@ -823,12 +825,20 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                 HIPCHK(hipMemcpyAsync(cmpF, f.data(), (size_t)960 * 576 * 4, hipMemcpyHostToDevice, e->stream));
                 HIPCHK(hipMemcpyAsync(cmpD, get(e, kd)->f(), (size_t)576 * 1536 * 4, hipMemcpyHostToDevice, e->stream));
                 launch_compose_f64(cmpF, cmpD, cmpQ, 960, 1536, 576, e->stream);
-                HIPCHK(hipMemcpy2DAsync(cmpCat, (size_t)2112 * 4, cmpF, (size_t)576 * 4, (size_t)576 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
-                HIPCHK(hipMemcpy2DAsync(cmpCat + 576, (size_t)2112 * 4, cmpQ, (size_t)1536 * 4, (size_t)1536 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
-                CHK(dev_alloc(e, &w.qkv2, (size_t)1024 * 2112));
-                launch_pack_weight(cmpCat, 960, 2112, 2112, w.qkv2, 1024, 2112, e->stream);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(e->stream));
+                if (e->fp8_decode) {
+                    // e4m3 decode weights: the composed part is quantised on its own (its rows have their own magnitude); the
+                    // W' part and the down weight of the launch are the unfused layer's e4m3 copies (qkv8, dn8)
+                    launch_pack_weight(cmpQ, 960, 1536, 1536, cmpCat, 1024, 1536, e->stream);
+                    HIPCHK(hipGetLastError());
+                    CHK(make_dec_fp8(e, cmpCat, 32, (1536 / 8) * 64, 32, &w.q2h8, &w.q2h_sc));
+                } else {
+                    HIPCHK(hipMemcpy2DAsync(cmpCat, (size_t)2112 * 4, cmpF, (size_t)576 * 4, (size_t)576 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
+                    HIPCHK(hipMemcpy2DAsync(cmpCat + 576, (size_t)2112 * 4, cmpQ, (size_t)1536 * 4, (size_t)1536 * 4, 960, hipMemcpyDeviceToDevice, e->stream));
+                    CHK(dev_alloc(e, &w.qkv2, (size_t)1024 * 2112));
+                    launch_pack_weight(cmpCat, 960, 2112, 2112, w.qkv2, 1024, 2112, e->stream);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(e->stream));
+                }
             }
             std::vector<float> gf((size_t)I * H), uf((size_t)I * H);
             for (int n = 0; n < I; ++n)
@@ -1173,6 +1183,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
         float* p = e->dec.p;
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
+        a.a8 = e->fp8_decode_act ? 1 : 0;
         a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
         a.row_of_slot = nullptr;
         // (and the logits store off: the taps mellow_lm_prefill / mellow_lm_decode_step read dlogits, generation does not)
@@ -1335,7 +1346,7 @@ static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int 
         float* vc = e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         // fused_in: this layer's q/k/v slabs (and the down slabs of x_new) were written by the previous layer's dec_qkv2 launch
-        const bool fused_in = l > l_begin && w.qkv2 != nullptr && !same_w;
+        const bool fused_in = l > l_begin && (w.qkv2 != nullptr || w.q2h8 != nullptr) && !same_w;
         DecArgs a = e->da;
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
         a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
@@ -1354,12 +1365,13 @@ static int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int 
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
           if (w.gu8) launch_dec_gateup(e->da, w.gu8, s, w.gu_sc);
           else launch_dec_gateup(e->da, w.gu16, s); }
-        const float* next_qkv2 = (l + 1 < l_end && !same_w) ? e->layers[l + 1].qkv2 : nullptr;
-        if (next_qkv2) {
+        const LMLayerW* nx = (l + 1 < l_end && !same_w) ? &e->layers[l + 1] : nullptr;
+        if (nx && (nx->qkv2 || nx->q2h8)) {
             // the down projection of this layer and the q/k/v projection of the next one as one launch (decode.hip, dec_qkv2_kernel)
             if (!(skip & 16))
-            { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * 4);
-              launch_dec_qkv2(e->da, next_qkv2, w.down.p, s); }
+            { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * (nx->q2h8 ? 1 : 4));
+              if (nx->q2h8) launch_dec_qkv2_w8(e->da, nx->qkv8, nx->qkv_sc, nx->q2h8, nx->q2h_sc, w.dn8, w.dn_sc, s);
+              else launch_dec_qkv2(e->da, nx->qkv2, w.down.p, s); }
         } else if (!(skip & 16))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
           if (w.dn8) launch_dec_down(e->da, w.dn8, w.down.KP / 8, s, w.dn_sc);
@@ -1468,6 +1480,29 @@ int mellow_lm_decode_step(mellow_engine_t* e, const int32_t* token_ids, float* l
         HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// Numeric tap of the decode step's lm_head kernel (dec_fullk_kernel) on caller-supplied rows: logits[B][vocab] = x[B][hidden] .
+// lm_head^T with the engine's own head weights -- the e4m3 copy when the engine holds one (fp8 mode), and then act_fp8 selects
+// whether the activations are quantised in the kernel (fp8 matrix pipe) or stay fp32.  x and logits are device buffers.
+int mellow_debug_dec_head(mellow_engine_t* e, const float* x, int B, int act_fp8, float* logits) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!x || !logits || B <= 0 || B > 1024) return fail("bad argument");
+    if (e->cfg.hidden_size != 576) return fail("the decode kernels are built for hidden size 576");
+    HIPCHK(hipSetDevice(e->device));
+    CHK(ensure_lm(e, B, 1, 2));
+    DecArgs a = e->da;
+    a.blk_live = nullptr; a.row_of_slot = nullptr;
+    a.a8 = (act_fp8 && e->head8) ? 1 : 0;
+    a.xnF = a.xmidF;                                  // dec_load_rows writes the F32-layout operand there
+    launch_dec_load_rows(a, B, x, 576, nullptr, 1, 0, e->stream);
+    if (e->head8) launch_dec_lm_head(a, e->head8, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream, e->head_sc);
+    else launch_dec_lm_head(a, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream);
+    HIPCHK(hipMemcpyAsync(logits, e->dlogits.p, (size_t)B * e->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->cur_B = 0;                                     // the decode state of an earlier prefill is gone
     return 0;
 }
 
@@ -1985,6 +2020,8 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     // developer / test knobs of the fp8 mode (read here, per engine): which half of the path reads e4m3 weights
     const char *fd = getenv("MELLOW_FP8_DECODE"), *fp = getenv("MELLOW_FP8_PREFILL");
     e->fp8_decode = e->fp8 && !(fd && fd[0] == '0');
+    const char* fa = getenv("MELLOW_FP8_DECODE_ACT");
+    e->fp8_decode_act = e->fp8_decode && !(fa && fa[0] == '0');
     e->fp8_prefill = !(fp && fp[0] == '0');
     e->f32x3_terms = 0;
     if (mode == MELLOW_PRECISION_F32X3) {
@@ -2006,7 +2043,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     HIPCHK(hipStreamSynchronize(parent->stream));
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
-    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
+    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;
     c->bn_alpha = parent->bn_alpha; c->bn_beta = parent->bn_beta;

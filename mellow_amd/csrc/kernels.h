@@ -146,6 +146,7 @@ struct DecArgs {
     // token record, its stop flag).  dec_compact_kernel repacks the rows that are still running into the lowest slots
     // whenever that empties a whole 32-row block.
     const int32_t* row_of_slot = nullptr;
+    int a8 = 0;                    // fp8 mode: launches that get e4m3 weights also quantise their activations (fp8 matrix pipe)
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
@@ -158,6 +159,10 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
 // down projection of a layer + q/k/v projection of the next one: Wq2 = P-layout [30][Q2_K8] of [W'_{l+1} | W'_{l+1} Wd_l],
 // Wd = this layer's down weight in P-layout (K8p = 192)
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
+// the same launch on e4m3 weights: the unfused layer's q/k/v copy (72 k-tiles per n-tile), the composed W' Wd (192) and the
+// down copy, one scale per packed row each (launch_pack_dec_fp8)
+void launch_dec_qkv2_w8(const DecArgs& a, const float* Wx8, const float* sc_x, const float* Wh8, const float* sc_h,
+                        const float* Wd8, const float* sc_d, hipStream_t s);
 // C[M][N] = A[M][K] . B[K][N], fp64 accumulate, rounded once to fp32 (row-major device buffers)
 void launch_compose_f64(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
 int dec_attn_chunk_groups();   // 4-key groups one attention workgroup covers per pass

@@ -78,6 +78,7 @@ def load_library(path: Optional[str] = None):
         "mellow_debug_tap": (ci, [vp, C.c_char_p, vp, i64, P(i64)]),
         "mellow_debug_gemm_fp8": (ci, [vp, vp, ci, ci, vp, ci, vp, ci, vp]),
         "mellow_debug_gemm_f32": (ci, [vp, ci, vp, ci, ci, vp, ci, vp, ci, vp]),
+        "mellow_debug_dec_head": (ci, [vp, vp, ci, ci, vp]),
         "mellow_prof_enable": (ci, [vp, ci]),
         "mellow_prof_reset": (ci, [vp]),
         "mellow_prof_num_families": (ci, []),
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft",
-    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
+    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_debug_dec_head", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
 )
 
 
@@ -405,6 +406,13 @@ class Engine:
         self._chk(self.lib.mellow_debug_gemm_fp8(self.h, C.c_void_p(A.data_ptr()), M, K, C.c_void_p(W.data_ptr()), N,
                                                  C.c_void_p(out.data_ptr()), int(iters), ms if iters > 0 else None))
         return out, ((ms[0], ms[1]) if iters > 0 else None)
+
+    def debug_dec_head(self, x: torch.Tensor, act_fp8: bool = False) -> torch.Tensor:
+        """The decode step's lm_head kernel on the rows x [B, hidden] (device tensor) -> logits [B, vocab]."""
+        x = x.to(self.tdev).contiguous().float()
+        out = torch.empty((x.shape[0], self.lm.vocab_size), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.mellow_debug_dec_head(self.h, _ptr(x), x.shape[0], 1 if act_fp8 else 0, _ptr(out)))
+        return out
 
     def enable_taps(self, on: bool = True):
         self._chk(self.lib.mellow_debug_enable_taps(self.h, 1 if on else 0))

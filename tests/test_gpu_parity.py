@@ -836,11 +836,17 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
         if k.endswith("input_layernorm.weight") or k.endswith("post_attention_layernorm.weight"):
             sd[k] = torch.ones_like(sd[k])
     os.environ["MELLOW_FP8_PREFILL"] = "0"
+    os.environ["MELLOW_FP8_DECODE_ACT"] = "0"              # fp32 activations: the weights are the only quantised operand here
     try:
         e8 = Engine(device=0, precision="fp8")
     finally:
         del os.environ["MELLOW_FP8_PREFILL"]
-    e8.load_state_dict(sd)
+        del os.environ["MELLOW_FP8_DECODE_ACT"]
+    os.environ["MELLOW_DECODE_FUSE"] = "0"                 # the fused launch multiplies by W' Wd, which is not an e4m3 matrix
+    try:
+        e8.load_state_dict(sd)
+    finally:
+        del os.environ["MELLOW_DECODE_FUSE"]
     e32 = Engine(device=0)
     e32.load_state_dict(sd)
     a1, a2, ids = synth.make_batch(3)
@@ -869,6 +875,95 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
     rel = float((l8b - l0).pow(2).mean().sqrt() / l0.pow(2).mean().sqrt())
     assert 1e-3 < rel < 0.2, rel            # only the LAST layer's tail + lm_head run on e4m3 weights in a prefill call
     for e in (e8, e32, e0, e8b):
+        e.close()
+
+
+def _e4m3_grid(shape, gen):
+    """Random values that ARE e4m3 numbers (normal range, both signs)."""
+    x = torch.randn(shape, generator=gen).clamp(-3, 3) * 100.0
+    return x.to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def test_fp8_decode_activation_quantisation_is_exact_on_representable_rows(synth_sd):
+    """The activation half of the fp8 decode kernels (v_mfma_f32_32x32x16_fp8_fp8 / 16x16x32: e4m3 weights AND activations,
+    one activation scale per batch row and k-slice of a wave = amax / 448), pinned through the lm_head kernel
+    (`mellow_debug_dec_head`): rows whose every 72-column slice is (an e4m3 number) x 2^e with slice amax 448 x 2^e quantise
+    without loss, so the fp8-pipe result must equal the same kernel on fp32 activations up to fp32 summation order -- which
+    also proves that weight bytes and activation bytes meet at the same k inside the instruction.  A generic row then differs
+    at the e4m3 level (3-bit mantissa), not more."""
+    from mellow_amd.engine import Engine
+    e8 = Engine(device=0, precision="fp8")
+    e8.load_state_dict(synth_sd)
+    gen = torch.Generator().manual_seed(5)
+    for B in (3, 32, 40):
+        q = _e4m3_grid((B, 8, 72), gen)
+        q[:, :, 0] = 448.0 * torch.where(torch.rand((B, 8), generator=gen) < 0.5, -1.0, 1.0)      # every slice reaches the format's maximum
+        expo = torch.randint(-12, 6, (B, 8, 1), generator=gen).float()
+        x = (q * torch.exp2(expo)).reshape(B, 576)
+        x[0, 72:144] = 0.0                                  # an all-zero slice
+        ref = e8.debug_dec_head(x, act_fp8=False)
+        got = e8.debug_dec_head(x, act_fp8=True)
+        scale = float(ref.abs().max())
+        # (the fp8 instruction sums its 16 products with fewer guard bits than an fp32 FMA chain: measured 1.6e-5 of max,
+        #  the same class as the prefill GEMM's 1e-4 bound above; a mis-assigned k would be O(1))
+        _close(got, ref, rel=0, atol=1e-4 * scale, name=f"fp8-pipe lm_head on representable rows, B={B}")
+        assert torch.equal(got.argmax(-1), ref.argmax(-1))
+    xg = torch.randn((32, 576), generator=gen)
+    ref = e8.debug_dec_head(xg, act_fp8=False)
+    got = e8.debug_dec_head(xg, act_fp8=True)
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert 5e-3 < rel < 6e-2, rel                           # e4m3 rounding: 2^-4 / sqrt(3) = 3.6e-2 per element
+    e8.close()
+
+
+def test_fp8_decode_on_the_fp8_pipe_stays_near_the_fp32_activation_form(synth_sd):
+    """Whole decode steps, e4m3 weights in both engines, activations fp32 (MELLOW_FP8_DECODE_ACT=0) against e4m3 on the fp8
+    matrix pipe (the default of the fp8 mode): five GEMM kernels per layer quantise their inputs, so the logits differ at the
+    percent level -- a wrong lane/byte assignment in any of them would give an O(1) difference -- and stay deterministic."""
+    from mellow_amd.engine import Engine
+    os.environ["MELLOW_FP8_PREFILL"] = "0"
+    os.environ["MELLOW_FP8_DECODE_ACT"] = "0"
+    try:
+        ew = Engine(device=0, precision="fp8")
+    finally:
+        del os.environ["MELLOW_FP8_DECODE_ACT"]
+    try:
+        ea = Engine(device=0, precision="fp8")
+    finally:
+        del os.environ["MELLOW_FP8_PREFILL"]
+    ew.load_state_dict(synth_sd)
+    ea.load_state_dict(synth_sd)
+    # ... and the fp8 mode's fused launch (down of layer l + q/k/v of layer l+1 on the e4m3 copy of W' Wd, decode.hip) against
+    # the five-launch layer on the same engine settings
+    eu = Engine(device=0, precision="fp8")
+    os.environ["MELLOW_DECODE_FUSE"] = "0"
+    try:
+        eu.load_state_dict(synth_sd)
+    finally:
+        del os.environ["MELLOW_DECODE_FUSE"]
+    ef = Engine(device=0, precision="fp8")
+    ef.load_state_dict(synth_sd)
+    for B in (3, 40):
+        a1, a2, ids = synth.make_batch(B)
+        pre = ew.prefix(a1, a2, ids)
+        lw = ew.lm_prefill(pre, reserve=6)
+        la = ea.lm_prefill(pre, reserve=6)
+        lu = eu.lm_prefill(pre, reserve=6)
+        lf = ef.lm_prefill(pre, reserve=6)
+        for i in range(4):
+            rel = float((la - lw).pow(2).mean().sqrt() / lw.pow(2).mean().sqrt())
+            assert torch.isfinite(la).all() and 1e-3 < rel < 0.2, (B, i, rel)
+            if i > 0:                      # (a prefill call ends with one decode layer: nothing fused in it)
+                relf = float((lf - lu).pow(2).mean().sqrt() / lu.pow(2).mean().sqrt())
+                assert torch.isfinite(lf).all() and 1e-4 < relf < 0.2, (B, i, relf)
+            tok = lw.argmax(-1)
+            lw = ew.lm_decode_step(tok)
+            la = ea.lm_decode_step(tok)
+            lu = eu.lm_decode_step(tok)
+            lf = ef.lm_decode_step(tok)
+        la_again = ea.lm_prefill(pre, reserve=6)
+        assert torch.equal(la_again, ea.lm_prefill(pre, reserve=6))
+    for e in (ew, ea, eu, ef):
         e.close()
 
 
@@ -901,12 +996,15 @@ def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     assert agree >= 0.5, agree                                           # measured 0.625 (10 of 16 rows); chance is 1/49152
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
-    # config 5's batch (128, max_len 64): per-row quantisation keeps rows batch-independent, so the first 16 rows of the
-    # big batch must equal the small batch exactly
+    # config 5's batch (128, max_len 64): every quantisation scale belongs to one batch row, so the first 16 rows of the big
+    # batch must equal the small batch exactly -- for the same max_len: the reserved context fixes the key split of the decode
+    # attention, a different split is a different fp32 summation order, and an e4m3 rounding downstream can turn a 1e-7
+    # difference into a different token
     a1b, a2b, idsb = synth.make_batch(128)
     t128, _, n128, _ = e8.generate(a1b, a2b, idsb, max_len=64, stop_id=0, ignore_stop=True)
     assert t128.shape == (128, 64) and n128 == 64 and (t128 >= 0).all() and (t128 < 49152).all()
-    assert np.array_equal(t128[:16, :8], t8a)
+    t16, *_ = e8.generate(a1, a2, ids, max_len=64, stop_id=0, ignore_stop=True)
+    assert np.array_equal(t128[:16], t16)
     e8.close()
 
 
