@@ -200,7 +200,7 @@ def north_star_b64(L: int, precision: str):
 ALT_NOTES = {
     "f32": "exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), the mode the parity suite calls 'f32'; tokens identical to f32x3",
     "f32x3": "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)",
-    "fp8": "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill, e4m3 weights in the decode kernels; not bit-exact (DESIGN 6b)",
+    "fp8": "BASELINE config 5 numerics: e4m3 GEMMs in encoder + LM prefill, e4m3 weights and activations on the fp8 matrix pipe in the decode GEMM kernels; not bit-exact (DESIGN 6b)",
 }
 
 
@@ -238,7 +238,7 @@ def alt_modes(B: int, L: int, headline: str):
             torch.cuda.synchronize()
             res["fp8_b128"] = {"batch": 128, "value": round(2 * 128 / (time.perf_counter() - t0), 2), "unit": "responses/s",
                                "phase_ms": {k: round(v, 2) for k, v in e.last_phase_ms().items()},
-                               "note": "BASELINE configs[4] (fp8, B = 128, max_len 64) on one GPU; e4m3 GEMMs in encoder + prefill, e4m3 weights in the decode kernels (DESIGN 6b)"}
+                               "note": "BASELINE configs[4] (fp8, B = 128, max_len 64) on one GPU; e4m3 GEMMs in encoder + prefill and in the decode GEMM kernels (DESIGN 6b)"}
         e.close()
     return res
 
