@@ -1131,6 +1131,7 @@ static inline int rb_of(int B) { return (B + 31) / 32; }
 static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
 
 static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) {
+    if (B > 1024) return fail("batch of %d exceeds the 1024 rows one call takes (split it; the decode state block is sized for 32 row blocks)", B);
     if (ctx_end <= 0 || ctx_end > Tmax) ctx_end = Tmax;      // last context length the call will reach (<= page capacity)
     if (Tmax > 2048) return fail("prefix + max_len = %d exceeds the 2048-key decode attention limit", Tmax);
     if (Tmax > e->cfg.max_positions) return fail("prefix + max_len = %d exceeds max_positions %d", Tmax, e->cfg.max_positions);

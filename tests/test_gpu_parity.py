@@ -301,6 +301,30 @@ def test_multi_row_block_batch(engine):
     assert np.array_equal(t40[:3], t_lo) and np.array_equal(t40[35:40], t_hi)
 
 
+@pytest.fixture(scope="module")
+def batch1024():
+    return synth.make_batch(1024)
+
+
+def test_large_batches_keep_every_row_and_stay_deterministic(engine, batch1024):
+    """B = 300 (ten row blocks, the last ragged) and the largest batch one call takes, B = 1024 (32 row blocks, ~70 GB of
+    activations + KV pages: sized for the 288 GB part): every row equals the same example in a 32-row batch, two calls agree."""
+    a1, a2, ids = batch1024
+    t32, *_ = engine.generate(a1[:32], a2[:32], ids[:32], max_len=6, stop_id=0, ignore_stop=True)
+    for B in (300, 1024):
+        tb, lens, n, _ = engine.generate(a1[:B], a2[:B], ids[:B], max_len=6, stop_id=0, ignore_stop=True)
+        assert tb.shape == (B, 6) and n == 6 and (tb >= 0).all() and (tb < 49152).all()
+        assert np.array_equal(tb[:32], t32)
+        lo = B - 20
+        t_hi, *_ = engine.generate(a1[lo:B], a2[lo:B], ids[lo:B], max_len=6, stop_id=0, ignore_stop=True)
+        assert np.array_equal(tb[lo:B], t_hi)
+        tb2, *_ = engine.generate(a1[:B], a2[:B], ids[:B], max_len=6, stop_id=0, ignore_stop=True)
+        assert np.array_equal(tb, tb2)
+    with pytest.raises(Exception, match="exceeds the 1024 rows"):
+        engine.generate(np.concatenate([a1, a1[:1]]), np.concatenate([a2, a2[:1]]), np.concatenate([ids, ids[:1]]),
+                        max_len=2, stop_id=0, ignore_stop=True)
+
+
 @pytest.mark.parametrize("B,n_new", [(2, 90), (1, 1600)])
 def test_long_context_decode_matches_independent_prefill(engine, golden_dir, B, n_new):
     """Contexts beyond one attention chunk (> 448 keys) up to the engine's 2048-key limit (389 + 1600 = 1989 keys: five key
