@@ -550,14 +550,33 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
         X3Q_WAIT()                                                                               \
         __builtin_amdgcn_s_barrier();                                                            \
     }
-    for (int kt = 0; kt < KT; kt += 6) {
-        X3Q_ITER(kt + 0, 0, 1, fa0, fw0, fa1, fw1)
-        X3Q_ITER(kt + 1, 1, 2, fa1, fw1, fa0, fw0)
-        X3Q_ITER(kt + 2, 2, 0, fa0, fw0, fa1, fw1)
-        X3Q_ITER(kt + 3, 0, 1, fa1, fw1, fa0, fw0)
-        X3Q_ITER(kt + 4, 1, 2, fa0, fw0, fa1, fw1)
-        X3Q_ITER(kt + 5, 2, 0, fa1, fw1, fa0, fw0)
+    // A wave whose 64 columns lie entirely beyond the weight's rows (the second half of the last column tile when N is an odd
+    // multiple of 64: N = 576 -> 1 wave pair in 10, N = 960 -> 1 in 16) keeps its loading duty and its barriers but issues no
+    // MFMA: the matrix pipe it would have kept busy with zeros goes to the other workgroup of the CU.
+    const bool idle = pn * BN + wn * 64 >= g.Nw;            // wave-uniform
+#define X3Q_ITER_IDLE(T, S0)                                                                     \
+    if ((T) < KT) {                                                                              \
+        X3Q_ISSUE((T) + 3, S0)                                                                   \
+        X3Q_WAIT()                                                                               \
+        __builtin_amdgcn_s_barrier();                                                            \
     }
+    if (!idle) {
+        for (int kt = 0; kt < KT; kt += 6) {
+            X3Q_ITER(kt + 0, 0, 1, fa0, fw0, fa1, fw1)
+            X3Q_ITER(kt + 1, 1, 2, fa1, fw1, fa0, fw0)
+            X3Q_ITER(kt + 2, 2, 0, fa0, fw0, fa1, fw1)
+            X3Q_ITER(kt + 3, 0, 1, fa1, fw1, fa0, fw0)
+            X3Q_ITER(kt + 4, 1, 2, fa0, fw0, fa1, fw1)
+            X3Q_ITER(kt + 5, 2, 0, fa1, fw1, fa0, fw0)
+        }
+    } else {
+        for (int kt = 0; kt < KT; kt += 3) {
+            X3Q_ITER_IDLE(kt + 0, 0)
+            X3Q_ITER_IDLE(kt + 1, 1)
+            X3Q_ITER_IDLE(kt + 2, 2)
+        }
+    }
+#undef X3Q_ITER_IDLE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the clamped re-loads of the last tiles
 #undef X3Q_ISSUE
 #undef X3Q_FRAGS
