@@ -57,9 +57,10 @@ __device__ __forceinline__ float4 ldg_nt(const float4* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 #endif
 }
-// Decode weights in e4m3 (BASELINE config 5, `W8` variants of the five GEMM kernels): the SAME slot order as the fp32 layouts
+// Decode weights in e4m3 (BASELINE config 5, `W8` variants of the GEMM kernels): the SAME slot order as the fp32 layouts
 // (one float4 slot = one 4-byte word of four e4m3 values), one scale per packed weight row, applied to the reduced output.
-// The values are widened to fp32 in registers and multiplied on the fp32 matrix pipe: the activations stay fp32.
+// W8 == 1: the values are widened to fp32 in registers and multiplied on the fp32 matrix pipe, the activations stay fp32
+// (MELLOW_FP8_DECODE_ACT=0: the form the weight pin of the parity suite runs); W8 == 2, the mode's default: see ldw8 below.
 template <bool W8>
 __device__ __forceinline__ float4 ldw(const float* __restrict__ Wp, int64_t slot) {
     if constexpr (W8) {
