@@ -133,7 +133,8 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 constexpr int QW = MELLOW_QKV_WAVES;                 // compute waves: 3 x 3 k-tiles or 9 x 1
 constexpr int QKV_THREADS = QW * 64 < 256 ? 256 : QW * 64;
 template <int KCD, bool BLK, bool FIRST, int W8>      // W8: 0 fp32 weights, 1 e4m3 weights widened, 2 e4m3 weights and activations (fp8 MFMA)
-__global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
+__global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __restrict__ Wp, const float* __restrict__ xmidF_p,
+                                                              const float* __restrict__ dslabF_p, int K8p, const DecArgs a,
                                                               const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[QW * 16 * 64];
     __shared__ float ssq_s[QW * 32];
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const DecArgs a, c
     if (wave < QW) {
         const int k8_0 = (kc * QW + wave) * KPW;
         const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
-        const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
-        const float4* sb = reinterpret_cast<const float4*>(a.dslabF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        const float4* xb = reinterpret_cast<const float4*>(xmidF_p) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        const float4* sb = reinterpret_cast<const float4*>(dslabF_p) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         float4 w[KPW], x[KPW], sl[KPW][KCD > 0 ? KCD : 1];
         uint32_t w8[KPW];
 #pragma unroll
@@ -264,8 +265,13 @@ constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key group
 //      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
 //      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
 template <bool BLK, bool FUSED, bool ONE>
-__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_kernel(const DecArgs a, float* __restrict__ k_cache,
-                                                                  float* __restrict__ v_cache) {
+__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
+                                                                  const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
+                                                                  const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
+                                                                  const DecArgs a) {
+    // (the leading scalar arguments repeat fields of `a`: the first 14 dwords of the argument block are preloaded into SGPRs
+    //  by the command processor -- build.py, -amdgpu-kernarg-preload-count -- so the K/V and slab addresses do not wait for a
+    //  scalar load from the argument buffer at the start of every launch)
     __shared__ float ssq_part[3];
     __shared__ __attribute__((aligned(16))) float qs[3 * 64];            // RoPE'd, pre-scaled q
     __shared__ __attribute__((aligned(16))) float knew[64], vnew[64];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
         if (live == 0 || row < 0) return;       // the block has stopped / the slot is empty (workgroup-uniform)
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tmax = a.Tmax;
+    const int Tmax = Tmax_p;
     float* kpage = k_cache + ((int64_t)row * 3 + g) * Tmax * 64;
     float* vpage = v_cache + ((int64_t)row * 3 + g) * Tmax * 64;
     const int sub = lane >> 4, quad = lane & 15;   // lane -> (key sub, dim quad): a wave instruction = 4 keys x 64 dims
@@ -293,9 +299,9 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     const bool dbg = tid == 0 && g == 0 && b == 0 && sp == 0;
     kstamp(1, 0, dbg);
 #ifdef MELLOW_POS_VECTOR_LOAD
-    const int pos = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(a.d_pos));
+    const int pos = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(d_pos_p));
 #else
-    const int pos = *a.d_pos;        // keys 0..pos-1 are cached; the new key is key `pos`
+    const int pos = *d_pos_p;        // keys 0..pos-1 are cached; the new key is key `pos`
 #endif
     // prologue: the 320 projected values of this (row, kv head) -- q of 3 heads | k | v -- are the sums of the qkv kernel's
     // split-K slabs.  80 threads own one float4 of columns each (8 slab loads of 16 B; before: 512 threads x 16 dword loads),
@@ -304,13 +310,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     const int hsel = (tid >> 5) & 3, i = tid & 31;
     const int r = tid < 80 ? tid : 0;
     const int pcol = r < 48 ? (3 * g + (r >> 4)) * 64 + 4 * (r & 15) : r < 64 ? 576 + g * 64 + 4 * (r - 48) : 768 + g * 64 + 4 * (r - 64);
-    const float* prow = a.pq + (int64_t)b * 960 + pcol;
+    const float* prow = pq_p + (int64_t)b * 960 + pcol;
     constexpr int NPQ = FUSED ? Q2_NPQ : DEC_KC_QKV;
     float4 sl4[NPQ], sq4[2];
     if (tid < 80) {
 #pragma unroll
         for (int s = 0; s < NPQ; ++s)
-            sl4[s] = (MELLOW_DA_ABL & 4) ? make_float4(0.1f * s, 0.2f, 0.3f, 0.4f) : *reinterpret_cast<const float4*>(prow + (int64_t)s * a.rows * 960);
+            sl4[s] = (MELLOW_DA_ABL & 4) ? make_float4(0.1f * s, 0.2f, 0.3f, 0.4f) : *reinterpret_cast<const float4*>(prow + (int64_t)s * rows_p * 960);
         if (!FUSED) {
             sq4[0] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[0];
             sq4[1] = reinterpret_cast<const float4*>(a.ssq1 + (int64_t)b * DEC_KC_QKV)[1];
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     float4 xr4 = make_float4(0.f, 0.f, 0.f, 0.f), xd4[FUSED ? Q2_HC : 1];
     if (FUSED && tid < 144) {
         const int64_t fi = ((int64_t)(b >> 5) * 72 + (tid >> 1)) * 64 + (b & 31) + 32 * (tid & 1);      // f32_idx(rb, 72, m, 4 tid)
-        xr4 = reinterpret_cast<const float4*>(a.xmidF)[fi];
+        xr4 = reinterpret_cast<const float4*>(xmidF_p)[fi];
 #pragma unroll
         for (int s = 0; s < Q2_HC; ++s) xd4[s] = reinterpret_cast<const float4*>(a.dslabF)[(int64_t)s * a.slabF_stride4 + fi];
     }
     const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
-    const int gbeg = sp * a.gs;                                   // groups of 4 keys
-    const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + a.gs;
+    const int gbeg = sp * gs_p;                                   // groups of 4 keys
+    const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + gs_p;
     // The K/V stream of a workgroup (107 KB at 420 keys) is bound by what the memory side delivers per CU (~12 B/clk): a wave
     // that issues all 14 page loads up front sits in the issue queue for ~4 us, and the prologue's barriers wait for the
     // slowest wave.  So only the first DA_G1 key groups are requested before the prologue (enough bytes in flight to keep the
@@ -589,7 +595,9 @@ constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
 // Chosen per launch: 8 rows for a single row block (B <= 32: 52.8 -> 52.2 ms of decode per 63 steps), 16 rows otherwise (at
 // B = 64 the 288 eight-row workgroups no longer fit the 256 CUs: 76.3 -> 78.5 ms).  MELLOW_OPROJ_ROWS forces one form.
 template <bool BLK, int W8, int OP_ROWS>
-__global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs a, const float* __restrict__ Wp16,
+__global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* __restrict__ Wp16, const float* __restrict__ attF16_p,
+                                                                  const float* __restrict__ att_ml_p, const float* __restrict__ xnewR_p,
+                                                                  int RB_p, int rows_p, const DecArgs a,
                                                                   const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
     constexpr int K16 = 36, TPW = (K16 + OP_WAVES - 1) / OP_WAVES;
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
     const bool erow_ok = OP_ROWS == 16 || (em >> 3) == (part & 1);
     const int64_t erow = (int64_t)rb * 32 + mh * 16 + em;
     float4 xres = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (erow_ok) xres = *reinterpret_cast<const float4*>(a.xnewR + erow * 576 + nt * 16 + enq * 4);
+    if (erow_ok) xres = *reinterpret_cast<const float4*>(xnewR_p + erow * 576 + nt * 16 + enq * 4);
 
     float4 w[TPW], os[TPW][DEC_TS];
     uint32_t w8[TPW];
@@ -626,10 +634,10 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const DecArgs 
 #pragma unroll
         for (int s = 0; s < DEC_TS; ++s) {
             ms[i][s] = 0.f; ls[i][s] = 1.f; os[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);     // rows of another workgroup: x = 0
-            if (lrow) os[i][s] = reinterpret_cast<const float4*>(a.attF16)[((((int64_t)s * a.RB + rb) * 36 + tc) * 2 + mh) * 64 + lane];
+            if (lrow) os[i][s] = reinterpret_cast<const float4*>(attF16_p)[((((int64_t)s * RB_p + rb) * 36 + tc) * 2 + mh) * 64 + lane];
         }
         if (lrow) {
-            const float* mlp = a.att_ml + ((int64_t)h * a.rows + row) * DEC_TS * 2;
+            const float* mlp = att_ml_p + ((int64_t)h * rows_p + row) * DEC_TS * 2;
             if constexpr (DEC_TS == 2) {                     // (m, l) of both splits of the row: one 16-byte load
                 const float4 v = *reinterpret_cast<const float4*>(mlp);
                 ms[i][0] = v.x; ls[i][0] = v.y; ms[i][1] = v.z; ls[i][1] = v.w;
@@ -717,8 +725,8 @@ enum { OUT_LOGITS = 1 };
 #endif
 constexpr int LM_WAVES = MELLOW_LM_WAVES;
 template <int OUT, bool BLK, int W8>
-__global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
-                                                        const float* __restrict__ XF, int N, const float* __restrict__ wscale) {
+__global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
+                                                        int N, const DecArgs a, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[LM_WAVES * 16 * 64];
     constexpr int KPW = 72 / LM_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -822,7 +830,8 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const DecArgs 
 #endif
 constexpr int GU_WAVES = MELLOW_GU_WAVES;
 template <bool BLK, int W8>
-__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecArgs a, const float* __restrict__ Wp16,
+__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const float* __restrict__ Wp16, const float* __restrict__ xF16,
+                                                                     const float* __restrict__ ssq_in, const DecArgs a,
                                                                      const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[GU_WAVES * 8 * 64];
     constexpr int K16 = 36, TPW = K16 / GU_WAVES;
@@ -832,9 +841,9 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
     MELLOW_BLK_EXIT(rb)
     const int t0 = wave * TPW;
     const int64_t wslot = ((int64_t)nt * K16 + t0) * 64 + lane;
-    const float4* xp = reinterpret_cast<const float4*>(a.xmidF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
+    const float4* xp = reinterpret_cast<const float4*>(xF16) + (((int64_t)rb * 36 + t0) * 2) * 64 + lane;
     // epilogue thread (m = tid>>1, q = tid&1), tid < 64: its row's 36 sum-of-squares partials, issued up front
-    const float4* sq = reinterpret_cast<const float4*>(a.ssq + ((int64_t)rb * 32 + ((tid >> 1) & 31)) * 40);
+    const float4* sq = reinterpret_cast<const float4*>(ssq_in + ((int64_t)rb * 32 + ((tid >> 1) & 31)) * 40);
     float4 w[TPW], x0[TPW], x1[TPW], s4[9];
     uint32_t w8[TPW];
 #pragma unroll
@@ -923,8 +932,8 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const DecAr
 constexpr int DN_WAVES = MELLOW_DOWN_WAVES;
 static_assert(DN_WAVES >= 4 && 192 % (8 * DN_WAVES) == 0, "the epilogue needs 256 threads; waves must divide the k-tiles");
 template <bool BLK, int W8>
-__global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a, const float* __restrict__ Wp, int K8p,
-                                                                 const float* __restrict__ wscale) {
+__global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const float* __restrict__ Wp, const float* __restrict__ guF_p, int K8p,
+                                                                 const DecArgs a, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
     constexpr int KPW = 192 / (DEC_KC_DOWN * DN_WAVES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
     MELLOW_BLK_EXIT(rb)
     const int k8_0 = (kc * DN_WAVES + wave) * KPW;
     const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
-    const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
+    const float4* hp = reinterpret_cast<const float4*>(guF_p) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
     const bool dbg = tid == 0 && nt == 0 && kc == 0 && rb == 0;
     kstamp(4, 0, dbg);
     float4 w[KPW], h4[KPW];
@@ -1006,8 +1015,9 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const DecArgs a
 //   e4m3 (W8 != 0): three separately quantised matrices (the q/k/v copy of the unfused layer, the composed one, the down copy),
 //                   one scale per packed row each: sc_x, sc_h, sc_d; W8 == 2 also quantises x_mid / h per wave slice (see ldw8)
 template <bool BLK, int Q2W, int W8>
-__global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, const float* __restrict__ Wx, int K8x,
-                                                            const float* __restrict__ Wh, int K8h, const float* __restrict__ Wd,
+__global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restrict__ Wx, const float* __restrict__ Wh,
+                                                            const float* __restrict__ Wd, const float* __restrict__ xmidF_p,
+                                                            const float* __restrict__ guF_p, int K8x, int K8h, const DecArgs a,
                                                             const float* __restrict__ sc_x, const float* __restrict__ sc_h,
                                                             const float* __restrict__ sc_d) {
     __shared__ __attribute__((aligned(16))) float red[Q2W * 16 * 64];
@@ -1028,7 +1038,7 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, con
         nt = b % 30; slab = b / 30;
         const int k8_0 = slab * 36 + wave * XT;
         const int64_t wslot = ((int64_t)nt * K8x + k8_0) * 64 + lane;
-        const float4* xb = reinterpret_cast<const float4*>(a.xmidF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+        const float4* xb = reinterpret_cast<const float4*>(xmidF_p) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
         float4 w[XT], x[XT];
         uint32_t w8[XT];
 #pragma unroll
@@ -1062,7 +1072,7 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, con
         const int k8_0 = hc * (192 / Q2_HC) + wave * HT;
         const float* wbase = side ? Wd : Wh;
         const int64_t wslot = side ? ((int64_t)(nt - 30) * 192 + k8_0) * 64 + lane : ((int64_t)nt * K8h + k8_0) * 64 + lane;
-        const float4* hp = reinterpret_cast<const float4*>(a.guF) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
+        const float4* hp = reinterpret_cast<const float4*>(guF_p) + ((int64_t)rb * 192 + k8_0) * 64 + lane;
         float4 w[HT], h4[HT];
         uint32_t w8[HT];
 #pragma unroll
@@ -1123,17 +1133,18 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const DecArgs a, con
 // ----------------------------------------------------------------------------------------------------
 // final RMSNorm: xn = w * ((x_mid + sum down slabs) * rsqrt(mean^2 + eps)) -> F32-layout operand of the lm_head
 template <int KCD, bool BLK>
-__global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, const float* __restrict__ norm_w) {
+__global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __restrict__ norm_w, const float* __restrict__ xmidF_p,
+                                                             const float* __restrict__ dslabF_p, int64_t stride4_p, const DecArgs a) {
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (BLK && b == 0 && tid < 32) a.blk_snap[tid] = a.blk_live[tid];      // for this step's arg-max (kernels.h)
     MELLOW_BLK_EXIT(b >> 5)
     const int xi = tid < 144 ? tid : 0;
     const int64_t fi = f32_idx(b >> 5, 72, b & 31, xi * 4);
-    float4 v = reinterpret_cast<const float4*>(a.xmidF)[fi];
+    float4 v = reinterpret_cast<const float4*>(xmidF_p)[fi];
     float4 xs[KCD > 0 ? KCD : 1];
 #pragma unroll
-    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(a.dslabF)[(int64_t)s * a.slabF_stride4 + fi];
+    for (int s = 0; s < KCD; ++s) xs[s] = reinterpret_cast<const float4*>(dslabF_p)[(int64_t)s * stride4_p + fi];
     const float4 wv = reinterpret_cast<const float4*>(norm_w)[xi];
 #pragma unroll
     for (int s = 0; s < KCD; ++s) v = f4add(v, xs[s]);
@@ -1153,7 +1164,8 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const DecArgs a, co
 // arg-max over the lm_head's per-tile candidates, fused with the loop bookkeeping of reference wrapper.py:232-249:
 // record the token at column (*d_pos - T0 + 1), track stop ids, and gather its embedding row (embed_tokens,
 // wrapper.py:237) as the next step's residual stream (row-major + F32-layout).
-__global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n, int32_t* __restrict__ tokens,
+__global__ __launch_bounds__(256) void dec_argmax_kernel(const float* __restrict__ cand_val_p, const int32_t* __restrict__ cand_idx_p, int n,
+                                                         const DecArgs a, int32_t* __restrict__ tokens,
                                                          const float* __restrict__ embed, int write_x, const LoopArgs lp) {
     __shared__ float bv[4];
     __shared__ int bi[4];
@@ -1167,8 +1179,8 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const DecArgs a, int n,
     int idx = 0x7fffffff;
     if (!dead) {
         for (int i = tid; i < n; i += 256) {
-            const float v = a.cand_val[(int64_t)b * n + i];
-            const int id = a.cand_idx[(int64_t)b * n + i];
+            const float v = cand_val_p[(int64_t)b * n + i];
+            const int id = cand_idx_p[(int64_t)b * n + i];
             if (arg_better(v, id, best, idx)) { best = v; idx = id; }
         }
 #pragma unroll
@@ -1327,12 +1339,12 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 #define MELLOW_QKV(KCD, FIRST)                                                                              \
     do {                                                                                                    \
         const int mode_ = w8_mode(a, wscale);                                                                \
-        if (a.blk_live && mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
-        else if (a.blk_live && mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);   \
-        else if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);        \
-        else if (mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
-        else if (mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);            \
-        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, a, Wp, K8p, wscale);                       \
+        if (a.blk_live && mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);   \
+        else if (a.blk_live && mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);   \
+        else if (a.blk_live) hipLaunchKernelGGL((dec_qkv_kernel<KCD, true, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);        \
+        else if (mode_ == 2) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 2>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);            \
+        else if (mode_ == 1) hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 1>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);            \
+        else hipLaunchKernelGGL((dec_qkv_kernel<KCD, false, FIRST, 0>), grid, dim3(QKV_THREADS), 0, s, Wp, (const float*)a.xmidF, (const float*)a.dslabF, K8p, a, wscale);                       \
     } while (0)
     if (kcd == 0 && a.first) MELLOW_QKV(0, true);
     else if (kcd == 0) MELLOW_QKV(0, false);
@@ -1342,14 +1354,17 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 }
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
     const dim3 grid(3, a.rows, DEC_TS), block(DA_WAVES * 64);
+#define MELLOW_DA(BLKV, FUSEDV, ONEV)                                                                                    \
+    hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+                       (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a)
     // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)
     if (a.RB == 1 && !a.blk_live) {
-        if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true, true>), grid, block, 0, s, a, k_cache, v_cache);
-        else hipLaunchKernelGGL((dec_attn_kernel<false, false, true>), grid, block, 0, s, a, k_cache, v_cache);
-    } else if (a.blk_live && fused) hipLaunchKernelGGL((dec_attn_kernel<true, true, false>), grid, block, 0, s, a, k_cache, v_cache);
-    else if (a.blk_live) hipLaunchKernelGGL((dec_attn_kernel<true, false, false>), grid, block, 0, s, a, k_cache, v_cache);
-    else if (fused) hipLaunchKernelGGL((dec_attn_kernel<false, true, false>), grid, block, 0, s, a, k_cache, v_cache);
-    else hipLaunchKernelGGL((dec_attn_kernel<false, false, false>), grid, block, 0, s, a, k_cache, v_cache);
+        if (fused) MELLOW_DA(false, true, true); else MELLOW_DA(false, false, true);
+    } else if (a.blk_live && fused) MELLOW_DA(true, true, false);
+    else if (a.blk_live) MELLOW_DA(true, false, false);
+    else if (fused) MELLOW_DA(false, true, false);
+    else MELLOW_DA(false, false, false);
+#undef MELLOW_DA
 }
 // fp32 form: Wq2 = [30][Q2_K8] (W' | W' Wd);  e4m3 form (sc_x != null): three separately quantised matrices (kernel comment)
 static void launch_dec_qkv2_any(const DecArgs& a, const float* Wx, int K8x, const float* Wh, int K8h, const float* Wd,
@@ -1367,7 +1382,8 @@ static void launch_dec_qkv2_any(const DecArgs& a, const float* Wx, int K8x, cons
     //  the batch size -- a row's tokens would otherwise change with the number of row blocks around it)
     if (mode == 2) few = false;
 #define MELLOW_Q2(BLKV, WV, MODE) \
-    hipLaunchKernelGGL((dec_qkv2_kernel<BLKV, WV, MODE>), grid, dim3(WV * 64), 0, s, a, Wx, K8x, Wh, K8h, Wd, sc_x, sc_h, sc_d)
+    hipLaunchKernelGGL((dec_qkv2_kernel<BLKV, WV, MODE>), grid, dim3(WV * 64), 0, s, Wx, Wh, Wd, (const float*)a.xmidF, (const float*)a.guF, \
+                       K8x, K8h, a, sc_x, sc_h, sc_d)
 #define MELLOW_Q2_MODES(BLKV, WV)                  \
     do {                                           \
         if (mode == 2) MELLOW_Q2(BLKV, WV, 2);     \
@@ -1419,8 +1435,10 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const 
 #endif
 #define MELLOW_OPROJ(BLKV, W8V)                                                                                             \
     do {                                                                                                                    \
-        if (rows == 8) hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 8>), dim3(36, 4 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);  \
-        else hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 16>), dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), 0, s, a, Wp16, wscale);           \
+        if (rows == 8) hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 8>), dim3(36, 4 * a.RB), dim3(OP_WAVES * 64), 0, s, Wp16,  \
+                                          (const float*)a.attF16, (const float*)a.att_ml, (const float*)a.xnewR, a.RB, a.rows, a, wscale); \
+        else hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 16>), dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), 0, s, Wp16,          \
+                                (const float*)a.attF16, (const float*)a.att_ml, (const float*)a.xnewR, a.RB, a.rows, a, wscale);           \
     } while (0)
     const int mode = w8_mode(a, wscale);
     if (a.blk_live && mode == 2) MELLOW_OPROJ(true, 2);
@@ -1432,29 +1450,29 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const 
 #undef MELLOW_OPROJ
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
-    MELLOW_LAUNCH_BLK_W8(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), a, Wp16);
+    MELLOW_LAUNCH_BLK_W8(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), Wp16, a.xmidF16, a.ssq, a);
 }
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s, const float* wscale) {
-    MELLOW_LAUNCH_BLK_W8(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), a, Wp, K8p);
+    MELLOW_LAUNCH_BLK_W8(dec_down_kernel, dim3(18, DEC_KC_DOWN, a.RB), dim3(DN_WAVES * 64), Wp, (const float*)a.guF, K8p, a);
 }
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s) {
     if (kcd == 0) {
-        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<0, true>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
-        else hipLaunchKernelGGL((dec_final_norm_kernel<0, false>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<0, true>), dim3(a.rows), dim3(192), 0, s, norm_w, (const float*)a.xmidF, (const float*)a.dslabF, a.slabF_stride4, a);
+        else hipLaunchKernelGGL((dec_final_norm_kernel<0, false>), dim3(a.rows), dim3(192), 0, s, norm_w, (const float*)a.xmidF, (const float*)a.dslabF, a.slabF_stride4, a);
     } else {
-        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, true>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
-        else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, false>), dim3(a.rows), dim3(192), 0, s, a, norm_w);
+        if (a.blk_live) hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, true>), dim3(a.rows), dim3(192), 0, s, norm_w, (const float*)a.xmidF, (const float*)a.dslabF, a.slabF_stride4, a);
+        else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, false>), dim3(a.rows), dim3(192), 0, s, norm_w, (const float*)a.xmidF, (const float*)a.dslabF, a.slabF_stride4, a);
     }
 }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale) {
     const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
     const int mode = w8_mode(a, wscale);
-    if (a.blk_live && mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 2>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (a.blk_live && mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 1>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 0>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 2>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else if (mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 1>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
-    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 0>), grid, block, 0, s, a, Wp, K8p, a.xnF, vocab, wscale);
+    if (a.blk_live && mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 2>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
+    else if (a.blk_live && mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 1>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
+    else if (a.blk_live) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 0>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
+    else if (mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 2>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
+    else if (mode == 1) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 1>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
+    else hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, false, 0>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);
 }
 // fp32 packed decode weight (P-layout: 32 rows per tile, or P16: 16 rows per tile; `slots` float4 slots per tile) -> one
 // 4-byte word of four e4m3 values per slot + one scale per packed row (amax / 448): one workgroup per tile
@@ -1494,7 +1512,8 @@ void launch_pack_dec_fp8(const float* Wp, int tiles, int slots_per_tile, int row
 }
 void launch_dec_argmax(const DecArgs& a, int B, int n_tiles, int32_t* tokens, const float* embed, int write_x,
                        const LoopArgs& loop, hipStream_t s) {
-    hipLaunchKernelGGL(dec_argmax_kernel, dim3(B), dim3(256), 0, s, a, n_tiles, tokens, embed, write_x, loop);
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(B), dim3(256), 0, s, (const float*)a.cand_val, (const int32_t*)a.cand_idx, n_tiles, a, tokens, embed,
+                       write_x, loop);
 }
 void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
                           int n_src, hipStream_t s) {
