@@ -108,6 +108,21 @@ __device__ __forceinline__ void a8_scales(float amax, float& inv, float& sc) {
     inv = amax > 0.f ? 448.0f / amax : 0.f;
     sc = amax * (1.0f / 448.0f);
 }
+// Stores of a kernel's OUTPUT (read by the next launch, on other XCDs).  Developer A/B (tools/ab_build.sh -DMELLOW_ST_MODE=n):
+// 0 plain (write-back in this XCD's L2, flushed by the release at the end of the kernel), 1 non-temporal, 2 write-through (sc0 sc1)
+#ifndef MELLOW_ST_MODE
+#define MELLOW_ST_MODE 0
+#endif
+__device__ __forceinline__ void st_out(float4* p, float4 v) {
+#if MELLOW_ST_MODE == 1
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#elif MELLOW_ST_MODE == 2
+    const f32x4 r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -537,7 +552,7 @@ _Pragma("unroll")                                                               
             const int head = 3 * g + hh, k = head * 64 + dq * 4;
             const int rb = b >> 5, m = b & 31;
             const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
-            reinterpret_cast<float4*>(a.attF16)[o4] = O;
+            st_out(reinterpret_cast<float4*>(a.attF16) + o4, O);
             if (dq == 0)      // (m, l) of this split: [head][row][split] pairs, so that the o_proj reads both splits of a row with one 16-byte load
                 *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
         }
@@ -705,8 +720,8 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         }
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
         const int k = nt * 16 + enq * 4;
-        reinterpret_cast<float4*>(a.xmidF)[f32_idx(rb, 72, mh * 16 + em, k)] = y;
-        reinterpret_cast<float4*>(a.xmidF16)[(((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq] = y;
+        st_out(reinterpret_cast<float4*>(a.xmidF) + f32_idx(rb, 72, mh * 16 + em, k), y);
+        st_out(reinterpret_cast<float4*>(a.xmidF16) + (((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq, y);
         float ss = f4ssq(y);
         ss += dpp_mov<0xB1>(ss);             // sum over the quad (the 4 column groups of one row)
         ss += dpp_mov<0x4E>(ss);
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const float
             h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
         }
         // hidden unit k = 8*nt + 4*q + r: down k-tile nt, F32-layout lane' = m + 32*q
-        reinterpret_cast<float4*>(a.guF)[((int64_t)rb * 192 + nt) * 64 + m + 32 * q] = make_float4(h[0], h[1], h[2], h[3]);
+        st_out(reinterpret_cast<float4*>(a.guF) + ((int64_t)rb * 192 + nt) * 64 + m + 32 * q, make_float4(h[0], h[1], h[2], h[3]));
     }
 }
 
@@ -1122,8 +1137,8 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
             for (int j = 0; j < 4; ++j) v[j] *= wsc[n + j];
         }
         const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (side) reinterpret_cast<float4*>(a.dslabF)[(int64_t)slab * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = o;
-        else *reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n) = o;
+        if (side) st_out(reinterpret_cast<float4*>(a.dslabF) + (int64_t)slab * a.slabF_stride4 + f32_idx(rb, 72, mm, n), o);
+        else st_out(reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n), o);
     }
     kstamp(7, 4, dbg);
 }
