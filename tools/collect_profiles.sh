@@ -13,6 +13,9 @@ python tools/pmc_traffic.py gemm $O/pf/f_counter_collection.csv $O/pw/w_counter_
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/df -o f --output-format csv -- python tools/pmc_decode.py > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/dw -o w --output-format csv -- python tools/pmc_decode.py > /dev/null 2>&1
 python tools/pmc_traffic.py decode $O/df/f_counter_collection.csv $O/dw/w_counter_collection.csv $O/pmc_decode_traffic.json
+# (per-kernel busy / waiting / L2-hit shares of the decode kernels: profiles/r03_pmc_decode_counters.txt was collected once with
+#  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY and
+#  --pmc TCC_HIT_sum TCC_MISS_sum over tools/pmc_decode.py, reduced with tools/pmc_decode_counters.py)
 # --- PMC: MFMA utilisation of the GEMM family / attentions ---
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $O/pm -o m --output-format csv -- python tools/pmc_prefill.py > $O/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $O/pm/m_counter_collection.csv $O/pmc_gemm_mfma.json || tail -5 $O/pmc_mfma.log
