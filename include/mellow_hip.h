@@ -174,6 +174,10 @@ int  mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, con
  * batch row and 72-column slice, fp8 matrix pipe).  Invalidates the decode state of an earlier prefill. */
 int  mellow_debug_dec_head(mellow_engine_t* e, const float* x, int B, int act_fp8, float* logits);
 
+/* (The library also exports three developer instrumentation entry points that are NOT part of this ABI and may change without
+ *  a version bump: mellow_dev_gemm_time, mellow_dev_prof_dump, mellow_dev_kdebug -- timers and stamps used by tools/, none of
+ *  them changes a result.) */
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * Per-kernel-family accounting with HIP events on the engine's stream.  When enabled, every launch
  * of a profiled family is bracketed by an event pair and its algorithmic work is accumulated;
