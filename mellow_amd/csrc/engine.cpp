@@ -121,6 +121,9 @@ struct mellow_engine {
     mellow_config_t cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    int prefill_parts = 2;                      // parts of the split LM prefill (MELLOW_PREFILL_SPLIT, read when the engine is created)
+    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};      // further streams of the split LM prefill (run_prefill)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
     bool owns_weights = true;                 // false for a context made by mellow_engine_fork: weight memory belongs to its parent
     std::map<std::string, HostTensor> host;   // until finalize
@@ -457,6 +460,12 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     e->cfg = *cfg;
     e->device = device;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (const char* pp = getenv("MELLOW_PREFILL_SPLIT")) e->prefill_parts = atoi(pp);
+    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&e->stream2[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
     const char* ng = getenv("MELLOW_NO_GRAPH");
     if (ng && ng[0] == '1') e->use_graph = false;
@@ -484,6 +493,11 @@ void mellow_engine_destroy(mellow_engine_t* e) {
         if (e->ev_phase[i]) hipEventDestroy(e->ev_phase[i]);
     if (e->d_tokens) hipFree(e->d_tokens);
     if (e->h_progress) hipHostFree(e->h_progress);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 3; ++i) {
+        if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]);
+        if (e->stream2[i]) hipStreamDestroy(e->stream2[i]);
+    }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -955,7 +969,7 @@ static int run_gemm(mellow_engine* e, const GemmArgs& a) {
 }
 // f32x3 mode, LM prefill: the activation arrives pre-split in APB order from its producer (a3) and both operands are staged
 // by LDS-DMA (gemm_x3q_kernel); counted in the same profile family as every other dense GEMM
-static int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3) {
+static int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_t st = nullptr) {
     auto it = e->bf_w.find(a.Wp);
     if (it == e->bf_w.end()) return fail("internal: no bf16-split copy of this weight");
     GemmArgs g = a;
@@ -963,7 +977,7 @@ static int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3) {
     g.W8 = reinterpret_cast<const uint8_t*>(it->second);
     ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
     ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 300;
-    launch_gemm_bf16x3_apb(g, e->stream);
+    launch_gemm_bf16x3_apb(g, st ? st : e->stream);
     return 0;
 }
 static GemmArgs lin(const float* A, int64_t lda, int M, const Packed& w, float* C, int64_t ldc, const float* bias) {
@@ -1142,7 +1156,7 @@ static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) 
     CHK(ensure(e, e->lm_o, Mp * 576));
     CHK(ensure(e, e->lm_h, Mp * 1536));
     if (e->f32x3_terms) {                       // 6 bytes per element, rows padded to whole 128-row panels
-        const size_t Mq = (size_t)rup((int)Mp, 128);
+        const size_t Mq = (size_t)rup((int)Mp, 128) + 3 * 128;   // + three panels: every part of the split prefill starts on a panel boundary
         CHK(ensure(e, e->lm_xn3, Mq * 576 * 6 / 4));
         CHK(ensure(e, e->lm_o3, Mq * 576 * 6 / 4));
         CHK(ensure(e, e->lm_h3, Mq * 1536 * 6 / 4));
@@ -1261,48 +1275,87 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bo
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
     static const bool no_apb = getenv("MELLOW_X3_NO_APB") != nullptr;        // developer A/B: the register-staged x3p kernel
     const bool apb = e->f32x3_terms && !no_apb;
+    // Split prefill (f32x3 mode): the batch is cut into independent parts (2 by default) that run the same launches on their own
+    // streams, so the tails and the fill / drain of one part's kernels are covered by another's (every buffer is indexed by row
+    // or by example, so a part is an offset; its pre-split operands get their own panel-aligned region).  Measured before it was
+    // built with two forked contexts (tools/half_chain_probe.py).  MELLOW_PREFILL_SPLIT=n: n parts (1 = one chain, at most 4).
+    int nh = (apb && !e->prof_on && e->stream2[0] != nullptr) ? e->prefill_parts : 1;
+    nh = nh < 1 ? 1 : (nh > 4 ? 4 : nh);
+    if (nh > B) nh = B;
+    int hb0[4], hB[4];
+    size_t prow[4];                                              // first row of each part's panel range
+    hipStream_t hs[4] = {s, e->stream2[0], e->stream2[1], e->stream2[2]};
+    for (int h = 0, b0 = 0, r = 0; h < nh; ++h) {
+        hb0[h] = b0; hB[h] = B / nh + (h < B % nh ? 1 : 0); prow[h] = (size_t)r;
+        b0 += hB[h]; r += rup(hB[h] * T, 128);
+    }
+    const bool split = nh > 1;
+    if (split) {
+        HIPCHK(hipEventRecord(e->ev_fork, s));
+        for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(hs[h], e->ev_fork, 0));
+    }
     for (int l = 0; l < NL; ++l) {
         const LMLayerW& w = e->layers[l];
-        float* kc = e->kcache.p + kv_layer_floats(e) * l;
-        float* vc = e->vcache.p + kv_layer_floats(e) * l;
-        // f32x3 mode: every GEMM input of the layer is written by its producer already split into three bf16 pieces, in the
-        // order the GEMM's LDS stage wants it (APB, common.h), and the GEMM stages both operands by LDS-DMA (x3q)
-        if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * M * 576 * 4); launch_rmsnorm_apb(x, e->lm_xn3.p, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
-        else { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.in_ln, e->cfg.rms_norm_eps, s); }
-        {
-            GemmArgs g;
-            g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.qkv.p; g.Nw = 960; g.N = 960; g.epi = EPI_QKV_ROPE;
-            g.q_out = e->lm_q.p; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
-            g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
-            if (apb) CHK(run_gemm_apb(e, g, e->lm_xn3.p)); else CHK(run_gemm(e, g));
+        bool last = false;
+        for (int h = 0; h < nh; ++h) {
+            hipStream_t st = hs[h];
+            const int64_t r0 = (int64_t)hb0[h] * T;
+            const int Mh = hB[h] * T, Bh = hB[h];
+            float* xh = x + r0 * 576;
+            float* xnh = xn + r0 * 576;
+            float* qh = e->lm_q.p + r0 * 576;
+            float* oh = e->lm_o.p + r0 * 576;
+            float* hh = e->lm_h.p + r0 * 1536;
+            float* kc = e->kcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
+            float* vc = e->vcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
+            // pre-split operand regions of this half (6 bytes per element, whole 128-row panels)
+            char* xn3 = apb ? reinterpret_cast<char*>(e->lm_xn3.p) + prow[h] * 576 * 6 : nullptr;
+            char* o3 = apb ? reinterpret_cast<char*>(e->lm_o3.p) + prow[h] * 576 * 6 : nullptr;
+            char* h3 = apb ? reinterpret_cast<char*>(e->lm_h3.p) + prow[h] * 1536 * 6 : nullptr;
+            // f32x3 mode: every GEMM input of the layer is written by its producer already split into three bf16 pieces, in the
+            // order the GEMM's LDS stage wants it (APB, common.h), and the GEMM stages both operands by LDS-DMA (x3q)
+            if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.in_ln, e->cfg.rms_norm_eps, st); }
+            else { ProfScope ps(e, PF_NORM, 0, 2.0 * Mh * 576 * 4); launch_rmsnorm(xh, xnh, Mh, 576, w.in_ln, e->cfg.rms_norm_eps, st); }
+            {
+                GemmArgs g;
+                g.A = xnh; g.lda = 576; g.M = Mh; g.K = 576; g.Wp = w.qkv.p; g.Nw = 960; g.N = 960; g.epi = EPI_QKV_ROPE;
+                g.q_out = qh; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
+                g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
+                if (apb) CHK(run_gemm_apb(e, g, xn3, st)); else CHK(run_gemm(e, g));
+            }
+            // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
+            // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
+            if (l == NL - 1 && !all_positions) { last = true; continue; }
+            {
+                // causal QK^T + PV: 4*64 flops per (query,key) pair per head
+                ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)Bh * ((double)T * (T + 1) / 2), 0);
+                static const bool attn_f32 = getenv("MELLOW_X3_ATTN") && getenv("MELLOW_X3_ATTN")[0] == '0';   // A/B: f32x3 mode on the fp32 kernel
+                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, e->f32x3_terms != 0 && !attn_f32, st);
+            }
+            {
+                GemmArgs g = lin(oh, 576, Mh, w.o, xh, 576, nullptr);
+                g.resid = xh; g.ldr = 576;
+                if (apb) CHK(run_gemm_apb(e, g, o3, st)); else CHK(run_gemm(e, g));
+            }
+            if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.post_ln, e->cfg.rms_norm_eps, st); }
+            else { ProfScope ps(e, PF_NORM, 0, 2.0 * Mh * 576 * 4); launch_rmsnorm(xh, xnh, Mh, 576, w.post_ln, e->cfg.rms_norm_eps, st); }
+            {
+                GemmArgs g;
+                g.A = xnh; g.lda = 576; g.M = Mh; g.K = 576; g.Wp = w.gateup.p; g.Nw = 3072; g.N = 1536; g.C = hh; g.ldc = 1536;
+                g.epi = EPI_SWIGLU;
+                if (apb) { g.C3 = h3; CHK(run_gemm_apb(e, g, xn3, st)); } else CHK(run_gemm(e, g));
+            }
+            {
+                GemmArgs g = lin(hh, 1536, Mh, w.down, xh, 576, nullptr);
+                g.resid = xh; g.ldr = 576;
+                if (apb) CHK(run_gemm_apb(e, g, h3, st)); else CHK(run_gemm(e, g));
+            }
         }
-        // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
-        // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
-        if (l == NL - 1 && !all_positions) break;
-        {
-            // causal QK^T + PV: 4*64 flops per (query,key) pair per head
-            ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)B * ((double)T * (T + 1) / 2), 0);
-            static const bool attn_f32 = getenv("MELLOW_X3_ATTN") && getenv("MELLOW_X3_ATTN")[0] == '0';   // A/B: f32x3 mode on the fp32 kernel
-            launch_prefill_attention(e->lm_q.p, kc, vc, e->lm_o.p, apb ? e->lm_o3.p : nullptr, B, T, Tmax, e->f32x3_terms != 0 && !attn_f32, s);
-        }
-        {
-            GemmArgs g = lin(e->lm_o.p, 576, M, w.o, x, 576, nullptr);
-            g.resid = x; g.ldr = 576;
-            if (apb) CHK(run_gemm_apb(e, g, e->lm_o3.p)); else CHK(run_gemm(e, g));
-        }
-        if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * M * 576 * 4); launch_rmsnorm_apb(x, e->lm_xn3.p, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
-        else { ProfScope ps(e, PF_NORM, 0, 2.0 * M * 576 * 4); launch_rmsnorm(x, xn, M, 576, w.post_ln, e->cfg.rms_norm_eps, s); }
-        {
-            GemmArgs g;
-            g.A = xn; g.lda = 576; g.M = M; g.K = 576; g.Wp = w.gateup.p; g.Nw = 3072; g.N = 1536; g.C = e->lm_h.p; g.ldc = 1536;
-            g.epi = EPI_SWIGLU;
-            if (apb) { g.C3 = e->lm_h3.p; CHK(run_gemm_apb(e, g, e->lm_xn3.p)); } else CHK(run_gemm(e, g));
-        }
-        {
-            GemmArgs g = lin(e->lm_h.p, 1536, M, w.down, x, 576, nullptr);
-            g.resid = x; g.ldr = 576;
-            if (apb) CHK(run_gemm_apb(e, g, e->lm_h3.p)); else CHK(run_gemm(e, g));
-        }
+        if (last) break;
+    }
+    for (int h = 1; h < nh; ++h) {
+        HIPCHK(hipEventRecord(e->ev_join[h - 1], hs[h]));
+        HIPCHK(hipStreamWaitEvent(s, e->ev_join[h - 1], 0));
     }
     if (all_positions) {        // x = the hidden states after all layers, every position (mellow_lm_forward_logits)
         HIPCHK(hipGetLastError());
@@ -2062,6 +2115,12 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     c->bf_w = parent->bf_w; c->fp8_w = parent->fp8_w;
     c->resample_banks = parent->resample_banks;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->prefill_parts = parent->prefill_parts;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev_phase[i]));
     CHK(alloc_state_words(c));
     *out = c;

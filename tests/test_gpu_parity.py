@@ -775,6 +775,30 @@ def test_fused_and_five_launch_decode_layers_agree(engine_f32, synth_sd, monkeyp
         e5.close()
 
 
+def test_split_prefill_is_bit_identical_to_one_chain(synth_sd, monkeypatch):
+    """f32x3 mode runs the LM prefill as two independent half-batches on two streams (engine.cpp run_prefill; 1 / 3 / 4 parts by
+    MELLOW_PREFILL_SPLIT).  A row's arithmetic does not depend on which rows share its launch, so logits and tokens must be
+    BIT-identical to the one-chain form, for batches that split unevenly (3, 5), not at all (1) and into four parts (9)."""
+    from mellow_amd.engine import Engine
+    engs = {}
+    for parts in ("1", "2", "4"):
+        monkeypatch.setenv("MELLOW_PREFILL_SPLIT", parts)
+        engs[parts] = Engine(device=0, precision="f32x3")
+        engs[parts].load_state_dict(synth_sd)
+    monkeypatch.delenv("MELLOW_PREFILL_SPLIT")
+    for B in (1, 3, 5, 9):
+        a1, a2, ids = synth.make_batch(B)
+        pre = engs["1"].prefix(a1, a2, ids)
+        ref = engs["1"].lm_prefill(pre, reserve=4)
+        tref, *_ = engs["1"].generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
+        for parts in ("2", "4"):
+            assert torch.equal(engs[parts].lm_prefill(pre, reserve=4), ref), (B, parts)
+            t, *_ = engs[parts].generate(a1, a2, ids, max_len=6, stop_id=0, ignore_stop=True)
+            assert np.array_equal(t, tref), (B, parts)
+    for e in engs.values():
+        e.close()
+
+
 def test_fork_needs_a_loaded_engine_and_shares_its_answers(engine_f32):
     from mellow_amd.engine import Engine, EngineError
     raw = Engine(device=0)
