@@ -27,6 +27,8 @@ import statistics
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first GPU call: see mellow_amd/__init__.py
+
 import numpy as np
 import torch
 
@@ -292,7 +294,7 @@ def main():
         args.batch, args.max_len, args.precision = 128, 64, "fp8"
     # every MELLOW_* variable this process saw goes into the line; developer probes that change the answers (MELLOW_DEV_*,
     # honoured only by -DMELLOW_DEVPROBE builds) are refused outright: a number measured under one is not a measurement
-    mellow_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MELLOW_")}
+    mellow_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MELLOW_") or k == "GPU_MAX_HW_QUEUES"}
     bad = [k for k in mellow_env if k.startswith("MELLOW_DEV_")]
     if bad:
         print(f"bench.py: refusing to run with developer probes set: {bad}", file=sys.stderr)

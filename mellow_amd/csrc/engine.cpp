@@ -462,10 +462,7 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (const char* pp = getenv("MELLOW_PREFILL_SPLIT")) e->prefill_parts = atoi(pp);
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&e->stream2[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));      // (streams: on first use)
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
     const char* ng = getenv("MELLOW_NO_GRAPH");
     if (ng && ng[0] == '1') e->use_graph = false;
@@ -1279,9 +1276,11 @@ static int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bo
     // streams, so the tails and the fill / drain of one part's kernels are covered by another's (every buffer is indexed by row
     // or by example, so a part is an offset; its pre-split operands get their own panel-aligned region).  Measured before it was
     // built with two forked contexts (tools/half_chain_probe.py).  MELLOW_PREFILL_SPLIT=n: n parts (1 = one chain, at most 4).
-    int nh = (apb && !e->prof_on && e->stream2[0] != nullptr) ? e->prefill_parts : 1;
+    int nh = (apb && !e->prof_on) ? e->prefill_parts : 1;
     nh = nh < 1 ? 1 : (nh > 4 ? 4 : nh);
     if (nh > B) nh = B;
+    for (int h = 1; h < nh; ++h)
+        if (!e->stream2[h - 1]) HIPCHK(hipStreamCreateWithFlags(&e->stream2[h - 1], hipStreamNonBlocking));
     int hb0[4], hB[4];
     size_t prow[4];                                              // first row of each part's panel range
     hipStream_t hs[4] = {s, e->stream2[0], e->stream2[1], e->stream2[2]};
@@ -2115,12 +2114,15 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     c->bf_w = parent->bf_w; c->fp8_w = parent->fp8_w;
     c->resample_banks = parent->resample_banks;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->prefill_parts = parent->prefill_parts;
+    // Contexts that pipeline whole batches do not split their prefill: their overlap comes from each other, and HIP maps streams
+    // onto a handful of hardware queues -- with extra streams per context two contexts' main streams end up on ONE queue and
+    // serialise (measured: `pipelined` 543 -> 450 responses/s).  The parent stops splitting from its first fork on.
+    c->prefill_parts = 1;
+    parent->prefill_parts = 1;
+    for (int i = 0; i < 3; ++i)
+        if (parent->stream2[i]) { hipStreamDestroy(parent->stream2[i]); parent->stream2[i] = nullptr; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev_phase[i]));
     CHK(alloc_state_words(c));
     *out = c;
