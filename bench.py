@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--preset", choices=("configs1", "configs2", "configs4"), default=None,
                     help="BASELINE.json configs[i] per-GPU shapes: configs1 = the headline (batch 32, max_len 64; the default), "
                          "configs2 = batch 32/GPU (256 over 8 GPUs), max_len 300, configs4 = fp8 weights, batch 128/GPU, max_len 64")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="also measure N engine contexts (one weight copy, mellow_engine_fork) pipelining independent batches on this "
                          "GPU: the supplementary 'pipelined' object, never the headline value; 0 or 1 skips it")
     args = ap.parse_args()
