@@ -6,6 +6,9 @@ R=r03
 O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 # --- PMC: HBM-side traffic of the GEMM family (per launch) and of the decode step (per step) ---
+# (counter passes run the prefill as ONE chain: per-kernel counters of two overlapping launches would count each other's cycles,
+#  and bench.py's own per-family timing -- which switches the split off like every profiled run -- counts unsplit launches)
+export MELLOW_PREFILL_SPLIT=1
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o f --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o w --output-format csv -- python tools/pmc_prefill.py > /dev/null 2>&1
 python tools/pmc_traffic.py gemm $O/pf/f_counter_collection.csv $O/pw/w_counter_collection.csv $O/pmc_gemm_traffic.json
@@ -21,6 +24,7 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_
 python tools/pmc_mfma.py $O/pm/m_counter_collection.csv $O/pmc_gemm_mfma.json || tail -5 $O/pmc_mfma.log
 cp $O/pmc_gemm_traffic.json profiles/${R}_pmc_gemm_traffic.json     # bench.py prints `traffic` only from files whose source hash matches
 cp $O/pmc_decode_traffic.json profiles/${R}_pmc_decode_traffic.json
+unset MELLOW_PREFILL_SPLIT
 # --- bench lines ---
 timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_f32.json 2>/dev/null
