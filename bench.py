@@ -44,7 +44,16 @@ PMC_DECODE_FILE = "r03_pmc_decode_traffic.json"         # decode step (tools/pmc
 FFT_GFLOP_PER_CLIP = 0.051         # algorithmic cost of the STFT; the kernel runs it as a dense DFT GEMM (2.10 GF/clip)
 
 # algorithmic work per response at max_len = 64, prefix 389
-DENSE_GFLOP_PER_RESPONSE = 24.33 + 87.90          # encoder (2 clips) + LM prefill -> MFMA-bound part
+ENCODER_GFLOP_PER_RESPONSE = 24.33                  # 2 clips of 10 s: one 1024-frame crop each
+PREFILL_GFLOP_PER_RESPONSE = 87.90
+DENSE_GFLOP_PER_RESPONSE = ENCODER_GFLOP_PER_RESPONSE + PREFILL_GFLOP_PER_RESPONSE          # encoder + LM prefill -> MFMA-bound part
+
+
+def dense_gflop_per_response(clip_seconds: int) -> float:
+    """clips longer than 10 s run the encoder's long path (reference htsat.py:908-936): 7 crops of 1024 frames per
+    30 s clip, each a full encoder pass, averaged afterwards -- 7x the encoder FLOPs; the LM prefill (389 positions) is unchanged."""
+    crops = 1 if clip_seconds <= 10 else 7
+    return crops * ENCODER_GFLOP_PER_RESPONSE + PREFILL_GFLOP_PER_RESPONSE
 
 
 _T0 = time.time()
@@ -199,6 +208,46 @@ def north_star_b64(L: int, precision: str):
             "path_roofline_frac": round(t_roof * 1e3 / (dt * 1e3), 4)}
 
 
+def configs3_leg(precision: str, B: int = 64, L: int = 128, clip_seconds: int = 30):
+    """BASELINE configs[3] on this GPU (v0_s checkpoint layout = v0's, batch 64, 2 x 30 s clips -> the 7-crop long-mel encoder
+    path, max_len 128): 2 timed passes, phase split, two-phase path roofline with the 7x encoder FLOPs of SURVEY 8d."""
+    from mellow_amd import spec, synth
+    from mellow_amd.engine import Engine
+    e = Engine(device=0, precision=precision)
+    e.load_state_dict(synth.make_state_dict(0))
+    a1, a2, ids = synth.make_batch(B, n_samples=clip_seconds * spec.SAMPLE_RATE)
+    a1d, a2d, idsd = e._f32(a1), e._f32(a2), e._i32(ids)
+    e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ft = []
+    for _ in range(2):
+        _, _, _, ftm = e.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
+        ft.append(ftm)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    ph = e.last_phase_ms()
+    e.close()
+    fp8 = precision == "fp8"
+    peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32X3_TFLOPS if precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
+    gf = dense_gflop_per_response(clip_seconds)
+    dec_bytes = decode_algorithmic_bytes(B, L)
+    t_mfma, t_hbm = B * gf / (peak * 1e3), dec_bytes / (PEAK_HBM_GBS * 1e9)
+    enc_tf = B * 7 * ENCODER_GFLOP_PER_RESPONSE / ph["encode_ms"] if ph["encode_ms"] > 0 else 0.0      # GF / ms = TF/s
+    return {"workload": f"v0_s layout (= v0), batch {B}, 2x{clip_seconds}s 32kHz synthetic clips (7 encoder crops per clip = {B * 2 * 7} crops), "
+                        f"max_len={L}, greedy, fixed-length, 1 GPU",
+            "value": round(B / dt, 2), "unit": "responses/s", "ms_per_pass": round(dt * 1e3, 2),
+            "first_token_ms_p50": round(statistics.median(ft), 2), "phase_ms": {k: round(v, 2) for k, v in ph.items()},
+            "decode_ms_per_step": round(ph["decode_ms"] / (L - 1), 4),
+            "encoder_phase": {"achieved_tflops": round(enc_tf, 1), "peak": round(peak, 1), "frac": round(enc_tf / peak, 4),
+                              "note": "7 x 24.33 GF per response (SURVEY 8d) / the front-end + encoder + prefix phase time"},
+            "decode_roofline": {"bound": "hbm", "achieved": round(dec_bytes / (ph["decode_ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(dec_bytes / (ph["decode_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+            "path_roofline": {"t_roof_ms_per_pass": round((t_mfma + t_hbm) * 1e3, 3), "frac": round((t_mfma + t_hbm) / dt, 4),
+                              "dense_gflop_per_response": round(gf, 2),
+                              "definition": "F_dense/P_mfma(dtype) + Bytes_decode/8TB/s, F_dense = 7 x encoder + prefill (SURVEY 8d)"}}
+
+
 ALT_NOTES = {
     "f32": "exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), the mode the parity suite calls 'f32'; tokens identical to f32x3",
     "f32x3": "fp32 GEMMs as exact 3-way bf16 operand splits on the bf16 MFMA pipe; tokens identical to f32 (DESIGN 6c)",
@@ -281,15 +330,20 @@ def main():
                          "e4m3 GEMMs in the encoder's Swin linears and LM prefill; a different metric line)")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the supplementary fp8 / f32x3 measurements")
     ap.add_argument("--no-b64", action="store_true", help="skip the supplementary batch-64 (north_star) measurement")
-    ap.add_argument("--preset", choices=("configs1", "configs2", "configs4"), default=None,
+    ap.add_argument("--preset", choices=("configs1", "configs2", "configs3", "configs4"), default=None,
                     help="BASELINE.json configs[i] per-GPU shapes: configs1 = the headline (batch 32, max_len 64; the default), "
-                         "configs2 = batch 32/GPU (256 over 8 GPUs), max_len 300, configs4 = fp8 weights, batch 128/GPU, max_len 64")
+                         "configs2 = batch 32/GPU (256 over 8 GPUs), max_len 300, configs3 = batch 64, 2x30 s clips (the 7-crop long-mel "
+                         "encoder path), max_len 128, configs4 = fp8 weights, batch 128/GPU, max_len 64")
+    ap.add_argument("--clip-seconds", type=int, default=10, help="length of the synthetic clips (10, or 30 for the long-mel path)")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the supplementary BASELINE configs[3] measurement")
     ap.add_argument("--inflight", type=int, default=4,
                     help="also measure N engine contexts (one weight copy, mellow_engine_fork) pipelining independent batches on this "
                          "GPU: the supplementary 'pipelined' object, never the headline value; 0 or 1 skips it")
     args = ap.parse_args()
     if args.preset == "configs2":
         args.batch, args.max_len = 32, 300
+    elif args.preset == "configs3":
+        args.batch, args.max_len, args.clip_seconds = 64, 128, 30
     elif args.preset == "configs4":
         args.batch, args.max_len, args.precision = 128, 64, "fp8"
     # every MELLOW_* variable this process saw goes into the line; developer probes that change the answers (MELLOW_DEV_*,
@@ -327,8 +381,10 @@ def main():
     eng.load_state_dict(synth.make_state_dict(0))
     comm_dev = eng.tdev if backend == "nccl" else torch.device("cpu")      # where the collectives' buffers live
     B, L = args.batch, args.max_len
-    a1, a2, ids = synth.make_batch(B, first=rank * B)
+    from mellow_amd import spec as mspec
+    a1, a2, ids = synth.make_batch(B, first=rank * B, n_samples=args.clip_seconds * mspec.SAMPLE_RATE)
     a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
+    n_crops = 1 if args.clip_seconds <= 10 else 7
 
     def step():
         toks, lens, steps, ftm = eng.generate(a1d, a2d, idsd, max_len=L, top_p=0.8, temperature=1.0, stop_id=0,
@@ -416,9 +472,9 @@ def main():
         # whole-path two-phase roofline: t_roof = F_dense/P_mfma + Bytes_decode/BW_hbm
         fp8 = args.precision == "fp8"
         peak = PEAK_FP8_MFMA_TFLOPS if fp8 else PEAK_F32X3_TFLOPS if args.precision == "f32x3" else PEAK_F32_MFMA_TFLOPS
-        t_roof = DENSE_GFLOP_PER_RESPONSE / (peak * 1e3) * B + dec_bytes / (PEAK_HBM_GBS * 1e9)
+        t_roof = dense_gflop_per_response(args.clip_seconds) / (peak * 1e3) * B + dec_bytes / (PEAK_HBM_GBS * 1e9)
         out = {
-            "metric": f"audio-pair responses/sec (v0 167M, 2x10s clips, max_len={L}, greedy)" +
+            "metric": f"audio-pair responses/sec (v0 167M, 2x{args.clip_seconds}s clips, max_len={L}, greedy)" +
                       (" [fp8 e4m3 GEMMs, BASELINE config 5 numerics: NOT the fp32 headline]" if fp8 else "") +
                       (" [exact-fp32-MFMA mode]" if args.precision == "f32" else ""),
             "value": round(value, 2), "unit": "responses/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -428,7 +484,8 @@ def main():
                       "f32 accumulate: fp32-accurate, parity suite green; mel included, the STFT is an fp32 FFT; attentions and decode "
                       "on exact fp32 MFMA / VALU)" if args.precision == "f32x3" else "f32"),
             "data": "synthetic",
-            "config": {"workload": f"v0 167M, batch {B}/GPU, 2x10s 32kHz synthetic clips + 16-token prompts, max_len={L}, "
+            "config": {"workload": f"v0 167M, batch {B}/GPU, 2x{args.clip_seconds}s 32kHz synthetic clips"
+                                   f"{' (7 encoder crops per clip)' if n_crops > 1 else ''} + 16-token prompts, max_len={L}, "
                                    f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",
                        "global_batch": n_gpus * B, "max_len": L, "parallelism": f"dp{n_gpus}", "preset": args.preset or "configs1"},
             "ranks_seen": (dist.get_world_size() if world > 1 else 1),
@@ -471,14 +528,18 @@ def main():
             out["reference_semantics"] = ref_sem
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        if n_gpus == 1 and args.precision != "fp8" and not args.no_alt_modes:
+        std = args.clip_seconds == 10        # the supplementary legs below are defined on the 10 s workload
+        if n_gpus == 1 and args.precision != "fp8" and not args.no_alt_modes and std:
             _progress("leg: alt_modes")
             out["alt_modes"] = alt_modes(B, L, args.precision)
-        if n_gpus == 1 and args.inflight > 1:
+        if n_gpus == 1 and args.inflight > 1 and std:
             out["pipelined"] = pipelined(args.inflight, B, L, max(args.steps, 2 * args.inflight), args.precision)
-        if n_gpus == 1 and args.precision != "fp8" and not args.no_b64 and B != 64:
+        if n_gpus == 1 and args.precision != "fp8" and not args.no_b64 and B != 64 and std:
             _progress("leg: north_star_b64")
             out["north_star_b64"] = north_star_b64(L, args.precision)
+        if n_gpus == 1 and args.precision != "fp8" and not args.no_configs3 and args.preset != "configs3":
+            _progress("leg: configs3")
+            out["configs3"] = configs3_leg(args.precision)
         if n_gpus == 1 and not args.no_cpu_baseline:
             _progress("leg: cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(L)

@@ -207,14 +207,17 @@ int         mellow_set_graph(mellow_engine_t* e, int on);
 
 /* ---- numeric mode of the dense GEMMs of the encoder (Swin linears) and of LM prefill; call before the first
  *      mellow_engine_load_tensor.  The reference has no counterpart (fp32 ATen matmuls throughout).
- *   MELLOW_PRECISION_F32 (default): exact fp32 on v_mfma_f32_32x32x2_f32 -- the mode every parity claim refers to.
+ *   MELLOW_PRECISION_F32: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere (fmaf-chain accumulation, the closest arithmetic to the
+ *     reference's ATen matmuls); the parity suite runs in this mode AND in the default one with the same tolerances.
  *   MELLOW_PRECISION_FP8: BASELINE config 5 -- OCP e4m3 weights (per-output-channel scale) and activations (per-row
  *     scale, quantised on the fly), fp32 accumulate on v_mfma_f32_32x32x16_fp8_fp8; the GEMM kernels of the decode step read
  *     e4m3 weights and quantise their activations in registers (one scale per batch row and wave k-slice).  Front-end (STFT,
  *     mel), K % 64 != 0 layers, the attentions and the norms stay fp32.  Not bit-exact: report token agreement.
- *   MELLOW_PRECISION_F32X3 (experimental): fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into
- *     three bf16 terms, the six largest partial products (the rest is < 2^-23 |a*b|) are accumulated in fp32:
- *     fp32-accurate (error against fp64 measured <= the fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32. */
+ *   MELLOW_PRECISION_F32X3 (DEFAULT of mellow_engine_create, of the Python `Engine` / `MellowWrapper`, and the mode bench.py
+ *     reports): fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into three bf16 terms, the six largest
+ *     partial products (the rest is < 2^-23 |a*b|) are accumulated in fp32: fp32-accurate (error against fp64 measured <= the
+ *     fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32.  Every engine-level parity test (tolerances against the
+ *     reference's fp32 outputs, exact greedy tokens) runs in this mode and in MELLOW_PRECISION_F32. */
 #define MELLOW_PRECISION_F32 0
 #define MELLOW_PRECISION_FP8 1
 #define MELLOW_PRECISION_F32X3 2

@@ -82,9 +82,11 @@ def load_wav(path: str) -> Tuple[torch.Tensor, int]:
 
 
 def _sinc_resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
-    """Provenance: a close restatement, step for step, of the sinc-kernel routine of torchaudio (third party, BSD 2-Clause,
-    pinned by the reference at 2.0.1 -- NOT a file of the reference repository), kept that close on purpose: the resampled
-    samples are the encoder's input, so any other windowing would be a different model input."""
+    """Provenance: a close restatement, step for step, of the sinc-kernel routine of torchaudio (third party, BSD 2-Clause:
+    Copyright (c) 2017 Facebook Inc. (Soumith Chintala), licence text in /NOTICE; pinned by the reference at 2.0.1 -- NOT a
+    file of the reference repository), kept that close on purpose: the resampled samples are the encoder's input, so any other
+    windowing would be a different model input.  Checked against an independent fp64 time-domain evaluation of the same
+    published algorithm (oracle/resample_oracle.py) in tests/test_host_cpu.py and, for the device twin, tests/test_gpu_parity.py."""
     base_freq = min(orig, new) * rolloff
     width = math.ceil(lowpass_filter_width * orig / base_freq)
     idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig

@@ -617,10 +617,20 @@ __device__ __forceinline__ float audio_row_value(const float* __restrict__ p33, 
 __global__ __launch_bounds__(192) void prefix_assemble_kernel(const float* __restrict__ proj33,
                                                               const float* __restrict__ embed,
                                                               const int32_t* __restrict__ ids, int B, int text_len,
-                                                              int sep_id, int vocab, float* __restrict__ prefix) {
+                                                              int sep_id, int vocab, float* __restrict__ prefix,
+                                                              unsigned long long* __restrict__ bad_id_word) {
     const int pos = blockIdx.x, b = blockIdx.y;
     const int P = 2 * 129 + 2 + text_len;
     float* dst = prefix + ((int64_t)b * P + pos) * 576;
+    // a prompt id outside the vocabulary: the reference's embedding lookup raises IndexError (decoder.py:47).  The row is read
+    // clamped (never a wild read) and the call's error word -- mapped host memory, read by the host with the results -- is set:
+    // the range check costs no kernel and no synchronisation of its own (it was a torch min/max + two host syncs per call)
+    if (pos >= 260 && threadIdx.x == 0 && bad_id_word) {
+        const int id = ids[(int64_t)b * text_len + (pos - 260)];
+        if (id < 0 || id >= vocab)
+            __hip_atomic_store(bad_id_word, (1ull << 63) | ((unsigned long long)(unsigned)b << 32) | (unsigned)id, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int c = threadIdx.x; c < 576; c += 192) {
         float v;
         if (pos < 129) v = audio_row_value(proj33 + (int64_t)b * 33 * 576, pos, c);
@@ -632,9 +642,9 @@ __global__ __launch_bounds__(192) void prefix_assemble_kernel(const float* __res
     }
 }
 void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
-                            int sep_id, int vocab, float* prefix, hipStream_t s) {
+                            int sep_id, int vocab, float* prefix, unsigned long long* bad_id_word, hipStream_t s) {
     hipLaunchKernelGGL(prefix_assemble_kernel, dim3(260 + text_len, B), dim3(192), 0, s, proj33, embed, ids, B,
-                       text_len, sep_id, vocab, prefix);
+                       text_len, sep_id, vocab, prefix, bad_id_word);
 }
 __global__ __launch_bounds__(192) void downsample33_kernel(const float* __restrict__ proj33, float* __restrict__ out) {
     const int r = blockIdx.x, clip = blockIdx.y;

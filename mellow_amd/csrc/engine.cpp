@@ -467,7 +467,9 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     const char* ng = getenv("MELLOW_NO_GRAPH");
     if (ng && ng[0] == '1') e->use_graph = false;
     *out = e;
-    return 0;
+    // the default numeric mode (include/mellow_hip.h): fp32-accurate GEMMs on the bf16 matrix pipe -- the mode bench.py measures
+    // and every engine-level parity test runs (next to the exact-fp32 MFMA mode); mellow_engine_set_precision overrides it
+    return mellow_engine_set_precision(e, MELLOW_PRECISION_F32X3);
 }
 
 void mellow_engine_destroy(mellow_engine_t* e) {
@@ -1142,9 +1144,8 @@ static inline int rb_of(int B) { return (B + 31) / 32; }
 static inline size_t kv_layer_floats(const mellow_engine* e) { return (size_t)e->kv_B * 3 * e->kv_Tmax * 64; }
 
 static int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end = 0) {
-    if (B > 1024) return fail("batch of %d exceeds the 1024 rows one call takes (split it; the decode state block is sized for 32 row blocks)", B);
+    if (B > 1024) return fail("batch of %d exceeds the 1024 rows one pass takes (mellow_generate chunks larger batches itself; the decode state block is sized for 32 row blocks)", B);
     if (ctx_end <= 0 || ctx_end > Tmax) ctx_end = Tmax;      // last context length the call will reach (<= page capacity)
-    if (Tmax > 2048) return fail("prefix + max_len = %d exceeds the 2048-key decode attention limit", Tmax);
     if (Tmax > e->cfg.max_positions) return fail("prefix + max_len = %d exceeds max_positions %d", Tmax, e->cfg.max_positions);
     const size_t Mp = (size_t)B * T;
     CHK(ensure(e, e->lm_x, Mp * 576));
@@ -1489,9 +1490,19 @@ static int encode_pair_to_prefix(mellow_engine* e, const float* a1, const float*
     HIPCHK(hipMemcpyAsync(cat.p + (size_t)B * n_samples, a2, (size_t)B * n_samples * 4, hipMemcpyDeviceToDevice, e->stream));
     CHK(run_encoder(e, cat.p, 2 * B, n_samples, 0, 1, nullptr));
     { ProfScope ps(e, PF_MISC, 0, 0);
-      launch_prefix_assemble(e->proj33.p, e->embed, ids, B, e->cfg.text_len, e->cfg.sep_token_id, e->cfg.vocab_size, prefix_out, e->stream); }
+      launch_prefix_assemble(e->proj33.p, e->embed, ids, B, e->cfg.text_len, e->cfg.sep_token_id, e->cfg.vocab_size, prefix_out,
+                             e->d_progress + 1, e->stream); }
     HIPCHK(hipGetLastError());
     return 0;
+}
+// The prompt ids are range-checked on the device (prefix_assemble_kernel sets word 1 of the mapped progress block); the host
+// reads it once the stream is synchronised and fails like the reference's embedding lookup (IndexError in the Python binding).
+static void clear_bad_id(mellow_engine* e) { __atomic_store_n(e->h_progress + 1, 0ull, __ATOMIC_RELEASE); }
+static int check_bad_id(mellow_engine* e) {
+    const unsigned long long w = __atomic_load_n(e->h_progress + 1, __ATOMIC_ACQUIRE);
+    if (!w) return 0;
+    return fail("index out of range in self: prompt id %d of example %u is outside the vocabulary [0, %d)", (int)(unsigned)(w & 0xffffffffu),
+                (unsigned)((w >> 32) & 0x7fffffffu), e->cfg.vocab_size);
 }
 
 int mellow_prefix(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples, const int32_t* input_ids,
@@ -1500,9 +1511,10 @@ int mellow_prefix(mellow_engine_t* e, const float* audio1, const float* audio2, 
     if (!audio1 || !audio2 || !input_ids || !out) return fail("null argument");
     if (B <= 0) return fail("B must be positive");
     HIPCHK(hipSetDevice(e->device));
+    clear_bad_id(e);
     CHK(encode_pair_to_prefix(e, audio1, audio2, n_samples, input_ids, B, out));
     HIPCHK(hipStreamSynchronize(e->stream));
-    return 0;
+    return check_bad_id(e);
 }
 
 int mellow_lm_prefill(mellow_engine_t* e, const float* prefix, int B, int T, int reserve, float* logits) {
@@ -1687,27 +1699,77 @@ static int wait_ticket(mellow_engine* e, unsigned want, unsigned* nseen) {
     }
 }
 
+static int generate_pass(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
+                         const int32_t* input_ids, int B, int max_len, int stop_id,
+                         int ignore_stop, int32_t* out_tokens, int32_t* out_len, int32_t* out_steps, float* first_token_ms);
+// The reference's loop (wrapper.py:216-249) takes any number of examples.  One pass of the engine takes up to 1024 rows (32 row
+// blocks of loop state), so a larger batch runs as consecutive passes of <= 1024 rows on the same pages: examples are
+// independent, the token record of every pass lands at its rows of `out_tokens`, a pass that stopped before the longest one is
+// padded with -1 (never computed), and the reference's stop rule -- the loop ends at the first step at which EVERY row has
+// produced the stop id -- is the maximum over the passes (a row's own length never depends on other rows).
 int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
                     const int32_t* input_ids, int B, int max_len, float top_p, float temperature, int stop_id,
                     int ignore_stop, int32_t* out_tokens, int32_t* out_len, int32_t* out_steps, float* first_token_ms) {
     (void)top_p;
     (void)temperature;  // the reference's top-p/temperature path never changes the arg-max (wrapper.py:219-232)
-    const auto t_entry = std::chrono::steady_clock::now();
     if (!e || !e->finalized) return fail("engine not finalized");
     if (!audio1 || !audio2 || !input_ids || !out_tokens) return fail("null argument");
     if (B <= 0 || max_len <= 0) return fail("B and max_len must be positive");
+    constexpr int kPassRows = 1024;
+    if (B <= kPassRows)
+        return generate_pass(e, audio1, audio2, n_samples, input_ids, B, max_len, stop_id, ignore_stop, out_tokens, out_len, out_steps, first_token_ms);
+    int steps_all = 0, enq_all = 0, rep_all = 0;
+    float ph[3] = {0.f, 0.f, 0.f};
+    std::vector<int> pass_steps;
+    for (int r0 = 0; r0 < B; r0 += kPassRows) {
+        const int nb = B - r0 < kPassRows ? B - r0 : kPassRows;
+        int st = 0;
+        float ftm = 0.f;
+        CHK(generate_pass(e, audio1 + (size_t)r0 * n_samples, audio2 + (size_t)r0 * n_samples, n_samples, input_ids + (size_t)r0 * e->cfg.text_len,
+                          nb, max_len, stop_id, ignore_stop, out_tokens + (size_t)r0 * max_len, out_len ? out_len + r0 : nullptr, &st, &ftm));
+        if (r0 == 0 && first_token_ms) *first_token_ms = ftm;      // the first answers of the call: entry -> first token of the first pass
+        pass_steps.push_back(st);
+        steps_all = st > steps_all ? st : steps_all;
+        enq_all = e->last_steps_enqueued > enq_all ? e->last_steps_enqueued : enq_all;
+        rep_all += e->last_compactions;
+        for (int i = 0; i < 3; ++i) ph[i] += e->phase_ms[i];
+    }
+    // columns a pass never reached (it stopped before the longest pass): -1, like the rows of a block that stopped early
+    for (size_t p = 0; p < pass_steps.size(); ++p) {
+        const int r0 = (int)p * kPassRows, nb = B - r0 < kPassRows ? B - r0 : kPassRows;
+        if (pass_steps[p] >= steps_all) continue;
+        int32_t* dst = out_tokens + (size_t)r0 * max_len + pass_steps[p];
+        const size_t w = (size_t)(steps_all - pass_steps[p]) * sizeof(int32_t);
+        hipPointerAttribute_t at;
+        const bool on_device = hipPointerGetAttributes(&at, out_tokens) == hipSuccess && at.type == hipMemoryTypeDevice;
+        if (!on_device) (void)hipGetLastError();            // a plain host pointer is not an error here
+        if (on_device) HIPCHK(hipMemset2D(dst, (size_t)max_len * sizeof(int32_t), 0xff, w, nb));
+        else for (int r = 0; r < nb; ++r) memset(dst + (size_t)r * max_len, 0xff, w);
+    }
+    e->last_steps_enqueued = enq_all;
+    e->last_compactions = rep_all;
+    for (int i = 0; i < 3; ++i) e->phase_ms[i] = ph[i];
+    if (out_steps) *out_steps = steps_all;
+    return 0;
+}
+
+static int generate_pass(mellow_engine_t* e, const float* audio1, const float* audio2, int64_t n_samples,
+                         const int32_t* input_ids, int B, int max_len, int stop_id,
+                         int ignore_stop, int32_t* out_tokens, int32_t* out_len, int32_t* out_steps, float* first_token_ms) {
+    const auto t_entry = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int T = e->cfg.prefix_len;
     // KV page geometry in buckets of 64 positions, so that nearby max_len values share pages, key split and graphs
     int Tmax = rup(T + max_len, 64);
-    if (Tmax > e->cfg.max_positions || Tmax > 2048) Tmax = T + max_len;
+    if (Tmax > e->cfg.max_positions) Tmax = T + max_len;
     CHK(ensure_lm(e, B, T, Tmax, T + max_len));
     const int Bp = e->da.rows;
     CHK(ensure(e, e->out_tok, (size_t)Bp * max_len));
     HIPCHK(hipEventRecord(e->ev_phase[0], s));
     // loop state (the prefill's arg-max already records token 0 and publishes ticket 1)
     __atomic_store_n(e->h_progress, 0ull, __ATOMIC_RELEASE);
+    clear_bad_id(e);
     HIPCHK(hipMemsetAsync(e->d_nseen, 0, 3 * sizeof(int32_t), s));       // n_seen, arrive, ticket
     HIPCHK(hipMemsetAsync(e->d_seen, 0, 1024 * sizeof(int32_t), s));
     e->h_params[0] = max_len;
@@ -1823,6 +1885,7 @@ int mellow_generate(mellow_engine_t* e, const float* audio1, const float* audio2
     HIPCHK(hipMemcpyAsync(out_tokens, e->out_tok.p, toks.size() * sizeof(int32_t), hipMemcpyDefault, s));
     HIPCHK(hipMemcpyAsync(toks.data(), e->out_tok.p, toks.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    CHK(check_bad_id(e));        // a prompt id outside the vocabulary (flagged by prefix_assemble_kernel): the reference raises IndexError
     for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&e->phase_ms[i], e->ev_phase[i], e->ev_phase[i + 1]));
     if (first_token_ms) *first_token_ms = (float)first_ms;
     int ref_steps = steps_done;

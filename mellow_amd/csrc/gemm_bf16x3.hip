@@ -5,7 +5,8 @@
 //   TERMS = 6: drops a2*b3, a3*b2, a3*b3 (< 2^-23 |a*b| in total), the order of one fp32 rounding.
 // Accumulation order differs from the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32, so results are fp32-accurate, not
 // bit-identical to that kernel; tools/f32x3_check.py measures all three against an fp64 product.
-// Opt-in (MELLOW_PRECISION_F32X3); the default and every parity claim stay on the exact fp32 MFMA kernel.
+// This is the engine's default numeric mode (MELLOW_PRECISION_F32X3, include/mellow_hip.h); the parity suite runs in it and in
+// the exact fp32 MFMA mode (MELLOW_PRECISION_F32, gemm_f32.hip) with the same tolerances and exact tokens.
 //
 //   split_rows   A fp32 [M][K] -> A3 [M][K/8][3][8 bf16]                           (one wave per row, before each GEMM)
 //   pack_bf16x3  W fp32 P-layout -> PB [n/32][k/16][3][lane][8 bf16]               (once per tensor at load time)

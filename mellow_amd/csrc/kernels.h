@@ -248,7 +248,7 @@ void launch_crop_average(const float* in, int n, int n_crops, int64_t len, int64
 void launch_gelu(const float* in, float* out, int64_t n, hipStream_t s);
 // prefix [B][389][576] from proj33 [2B][33][576] (clips 0..B-1 = audio1, B..2B-1 = audio2)
 void launch_prefix_assemble(const float* proj33, const float* embed, const int32_t* ids, int B, int text_len,
-                            int sep_id, int vocab, float* prefix, hipStream_t s);
+                            int sep_id, int vocab, float* prefix, unsigned long long* bad_id_word, hipStream_t s);
 // out[i] = table[ids[i]] (rows of `width` floats, width % 4 == 0; ids clamped to [0, n_rows))
 void launch_gather_rows(const float* table, int width, const int32_t* ids, int n, int n_rows, float* out, hipStream_t s);
 // out [B][n][576] = in [B][T][576] rows from_pos .. from_pos + n - 1

@@ -2,7 +2,9 @@
 (SURVEY.md §8e): examples are independent, so each rank (one process per GPU) runs the whole hot path on a
 contiguous shard with its own weight replica, and the only communication is ONE all-gather of the generated
 token ids at the end (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
-The payload is tiny (int32 [B_local, max_len] + lengths), so the collective is latency-bound."""
+The payload is tiny (int32 [B_local, max_len] + lengths), so the collective is latency-bound.  The opt-in sharding of
+`MellowWrapper.generate` first checks that every rank holds the same examples -- through the rendezvous store, not through a
+second collective (`agree_on_examples`)."""
 from __future__ import annotations
 
 from typing import List, Tuple
@@ -17,6 +19,53 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     per = (n + world - 1) // world
     lo = min(n, rank * per)
     return lo, min(n, lo + per)
+
+
+_agree_calls = 0
+
+
+def examples_signature(examples) -> bytes:
+    """count + SHA-256 of a list of [audio1, audio2, prompt] examples.  File names and prompts are hashed as text; in-memory
+    audio (ndarray / tensor, the wrapper's extension) is hashed by CONTENT -- shape, dtype and the raw bytes of its contiguous
+    float32 form -- because `str()` of an array is numpy's summarised form ('[0.1 0.2 ... 0.3]') and two different clips can
+    print alike."""
+    import hashlib
+    h = hashlib.sha256()
+    n = 0
+    for ex in examples:
+        n += 1
+        for item in ex:
+            if isinstance(item, (str, bytes)) or hasattr(item, "__fspath__"):
+                b = item if isinstance(item, bytes) else str(item).encode()
+                h.update(b"s" + len(b).to_bytes(8, "little") + b)
+            else:
+                a = np.ascontiguousarray(torch.as_tensor(item).detach().cpu().numpy(), dtype=np.float32)
+                h.update(b"a" + repr(a.shape).encode() + a.tobytes())
+    return n.to_bytes(8, "little") + h.digest()
+
+
+def agree_on_examples(sig: bytes) -> None:
+    """Every rank must have been handed the same `examples` before they are sharded: the signatures are compared through the
+    process group's rendezvous STORE (host TCP to the store rank 0 already runs for torch.distributed): NOT a collective, no GPU
+    work, no RCCL call -- the token all-gather stays the one collective of a data-parallel `generate` (north_star).  It cannot
+    ride in that gather: ranks holding lists of different LENGTH would enter it with blocks of different size (undefined
+    behaviour under RCCL), which is exactly the case to refuse.  Raises ValueError on every rank when the lists differ."""
+    global _agree_calls
+    store = dist.distributed_c10d._get_default_store()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    _agree_calls += 1
+    c = _agree_calls                                     # every rank makes the same sequence of data-parallel calls
+    store.set(f"mellow_amd/examples/{c}/{rank}", sig)
+    sigs = [bytes(store.get(f"mellow_amd/examples/{c}/{r}")) for r in range(world)]      # get() waits for the key
+    if c > 1:          # every rank has published call c, hence finished reading call c - 1
+        try:
+            store.delete_key(f"mellow_amd/examples/{c - 1}/{rank}")
+        except Exception:
+            pass
+    if any(s != sigs[0] for s in sigs):
+        counts = [int.from_bytes(s[:8], "little") for s in sigs]
+        raise ValueError("data_parallel generate(): the ranks were given different `examples` "
+                         f"(counts {counts}); call it with the same list on every rank, or turn sharding off")
 
 
 def gather_tokens(tokens: np.ndarray, lengths: np.ndarray, n_total: int, max_len: int, device=None, per_rank: int = 0):

@@ -19,6 +19,7 @@ from .spec import LMConfig
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmellow_hip.so")
 ABI_VERSION = 2
+DEFAULT_PRECISION = "f32x3"      # = MELLOW_PRECISION_F32X3, what mellow_engine_create selects (include/mellow_hip.h)
 
 _F32, _I32, _I64 = 0, 1, 2
 
@@ -132,14 +133,17 @@ def _ptr(t: torch.Tensor) -> C.c_void_p:
 class Engine:
     """One engine per device.  Inputs/outputs are torch tensors on that device (plumbing only)."""
 
-    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: int = 2048,
-                 precision: str = "f32"):
+    def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: Optional[int] = None,
+                 precision: Optional[str] = None):
         self.lib = load_library()
         if self.lib.mellow_device_count() <= 0:
             raise EngineError("no HIP device visible: the Mellow engine needs an MI355X (no CPU fallback)")
         self.lm = lm or LMConfig.load()
         self.device = int(device)
         self.tdev = torch.device(f"cuda:{self.device}")
+        # positions the KV pages / RoPE tables may reach: the LM's own limit (8192 for SmolLM2-135M) unless the caller asks for
+        # less -- the reference's loop is bounded by nothing else (wrapper.py:216, decoder.py:25)
+        max_positions = int(max_positions) if max_positions else int(self.lm.max_position_embeddings)
         cfg = MellowConfig(
             abi_version=ABI_VERSION, vocab_size=self.lm.vocab_size, hidden_size=self.lm.hidden_size,
             intermediate_size=self.lm.intermediate_size, num_layers=self.lm.num_hidden_layers,
@@ -152,8 +156,10 @@ class Engine:
         self._chk(self.lib.mellow_engine_create(C.byref(cfg), self.device, C.byref(h)))
         self.h = h
         self.finalized = False
-        # "f32": exact fp32 MFMA GEMMs (default; the parity mode).  "fp8": BASELINE config 5, e4m3 GEMMs in the encoder's
-        # Swin linears and LM prefill (fp32 accumulate; decode and front-end stay fp32) -- not bit-exact.
+        # "f32x3" (default, = the library's default and the mode bench.py reports): fp32-accurate GEMMs as exact 3-way bf16 splits
+        # on the bf16 MFMA pipe.  "f32": exact fp32 MFMA GEMMs.  "fp8": BASELINE config 5 (e4m3 GEMMs, not bit-exact).
+        # The parity suite runs "f32x3" and "f32" with the same tolerances and exact tokens.  MELLOW_PRECISION overrides the default.
+        precision = precision or os.environ.get("MELLOW_PRECISION") or DEFAULT_PRECISION
         if precision not in ("f32", "fp8", "f32x3"):
             raise ValueError(f"unknown precision {precision!r}")
         self.precision = precision
@@ -163,6 +169,8 @@ class Engine:
     def _chk(self, rc: int):
         if rc != 0:
             msg = self.lib.mellow_last_error().decode("utf-8", "replace")
+            if msg.startswith("index out of range in self"):      # the reference's embedding lookup raises IndexError with this text
+                raise IndexError(msg)
             raise EngineError(msg)
 
     def close(self):
@@ -238,6 +246,21 @@ class Engine:
             raise IndexError("index out of range in self")
         return t.to(device=self.tdev, dtype=torch.int32).contiguous()
 
+    def _prompt_ids(self, x) -> torch.Tensor:
+        """prompt ids -> int32 on the device with NO torch kernel and NO synchronisation when they already are device int32 (the
+        timed path of bench.py): their range is checked on the device by prefix_assemble_kernel, which flags the call's error word;
+        the C call then fails with the reference's IndexError text.  Host arrays (what a tokenizer returns) are checked right here
+        in numpy; a device tensor of another dtype is clamped to [-1, vocab] before it is narrowed, so an out-of-range 64-bit id
+        cannot alias a valid 32-bit one."""
+        t = torch.as_tensor(x)
+        if t.device.type == "cpu":
+            a = t.numpy()
+            if a.size and (int(a.min()) < 0 or int(a.max()) >= self.lm.vocab_size):
+                raise IndexError("index out of range in self")
+        elif t.dtype != torch.int32:
+            t = t.clamp(-1, self.lm.vocab_size)
+        return t.to(device=self.tdev, dtype=torch.int32).contiguous()
+
     def _sync_inputs(self):
         """The engine runs on its own non-blocking HIP stream: device tensors produced by still-running torch kernels
         (resample / tile / cat on torch's current stream) must be complete before their raw pointers cross the C ABI."""
@@ -245,7 +268,7 @@ class Engine:
 
     def max_new_tokens_limit(self) -> int:
         """largest max_len the KV pages / RoPE tables of this engine can hold"""
-        return min(int(self.cfg.max_positions), 2048) - spec.PREFIX_LEN
+        return int(self.cfg.max_positions) - spec.PREFIX_LEN
 
     # ---- hot path ----------------------------------------------------------------------------------
     def generate(self, audio1, audio2, input_ids, max_len: int, top_p: float = 0.8, temperature: float = 1.0,
@@ -255,7 +278,7 @@ class Engine:
         call spent bringing host arrays to the device (latency from audio in HOST memory)."""
         import time
         t_in = time.perf_counter()
-        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._ids(input_ids)
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._prompt_ids(input_ids)
         B, n = a1.shape
         assert a2.shape == a1.shape and ids.shape == (B, spec.TEXT_LEN), (a1.shape, a2.shape, ids.shape)
         out = torch.empty((B, max_len), dtype=torch.int32, device=self.tdev)
@@ -300,7 +323,7 @@ class Engine:
         return out
 
     def prefix(self, audio1, audio2, input_ids) -> torch.Tensor:
-        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._ids(input_ids)
+        a1, a2, ids = self._f32(audio1), self._f32(audio2), self._prompt_ids(input_ids)
         B, n = a1.shape
         out = torch.empty((B, spec.PREFIX_LEN, spec.D_PROJ), dtype=torch.float32, device=self.tdev)
         self._sync_inputs()

@@ -25,7 +25,7 @@ class EnginePool:
     """`n_contexts` engines on one device; `generate_many` pipelines a list of batches over them."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_contexts: int = 2, device: int = 0,
-                 max_positions: int = 2048, lm: Optional[LMConfig] = None, precision: str = "f32"):
+                 max_positions: Optional[int] = None, lm: Optional[LMConfig] = None, precision: str = "f32"):
         if n_contexts < 1:
             raise ValueError("n_contexts must be >= 1")
         first = Engine(lm=lm, device=device, max_positions=max_positions, precision=precision)

@@ -34,7 +34,7 @@ import yaml
 
 from . import spec
 from .audio import load_audio_into_tensor
-from .engine import Engine, EngineError
+from .engine import DEFAULT_PRECISION, Engine, EngineError
 from .spec import LMConfig
 
 
@@ -59,14 +59,14 @@ class MellowWrapper:
     model_name = {"v0": "v0.ckpt", "v0_s": "v0_s.ckpt"}
 
     def __init__(self, config, model, device, use_cuda=True, *, checkpoint: Optional[str] = None,
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: int = 2048,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: Optional[int] = None,
                  data_parallel: Optional[bool] = None, precision: Optional[str] = None):
         """Reference signature `MellowWrapper(config, model, device, use_cuda=True)` (wrapper.py:35) plus keyword-only
         extensions: `checkpoint` (a local .ckpt instead of the hub download), `state_dict` (already loaded), `tokenizer`
-        (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; the decode
-        attention supports 2048 keys), `data_parallel` (True or MELLOW_DATA_PARALLEL=1: shard `generate` over the ranks of an
+        (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; default: the LM's
+        max_position_embeddings, 8192), `data_parallel` (True or MELLOW_DATA_PARALLEL=1: shard `generate` over the ranks of an
         initialised torch.distributed group, one process per GPU, every rank calling with the SAME examples -- checked; default
-        off: like the reference, every process answers its own examples), `precision` ("f32" | "f32x3" | "fp8")."""
+        off: like the reference, every process answers its own examples), `precision` ("f32x3" (default) | "f32" | "fp8")."""
         self.supported_versions = self.model_name.keys()
         if model not in self.supported_versions:
             raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
@@ -79,9 +79,9 @@ class MellowWrapper:
         self._tokenizer_override = tokenizer
         self._max_positions = max_positions
         self._data_parallel = data_parallel
-        # numeric mode of the dense GEMMs (include/mellow_hip.h): "f32" exact fp32 MFMA (default), "f32x3" fp32-accurate
-        # bf16-split, "fp8" BASELINE config 5; keyword or MELLOW_PRECISION
-        self._precision = precision or os.environ.get("MELLOW_PRECISION", "f32")
+        # numeric mode of the dense GEMMs (include/mellow_hip.h): "f32x3" fp32-accurate bf16-split (default = the mode
+        # bench.py reports), "f32" exact fp32 MFMA, "fp8" BASELINE config 5; keyword or MELLOW_PRECISION
+        self._precision = precision or os.environ.get("MELLOW_PRECISION") or DEFAULT_PRECISION
         self.model, self.tokenizer, self.args = self.get_model_and_tokenizer(config_path=self.config_path)
 
     # ---- construction -------------------------------------------------------------------------------------
@@ -211,22 +211,12 @@ class MellowWrapper:
         return 0, 1
 
     def _check_same_examples(self, examples):
-        """Sharding is only meaningful when every rank was handed the same list: compare (count, digest) across ranks and
-        raise on every rank otherwise (a silent mismatch would return other ranks' texts, or hang in the gather)."""
-        import hashlib
-        import torch.distributed as dist
+        """Sharding is only meaningful when every rank was handed the same list: compare (count, content digest) across ranks and
+        raise on every rank otherwise (a silent mismatch would return other ranks' texts, or hang in the gather).  The exchange
+        runs over the process group's rendezvous store (mellow_amd.dist.agree_on_examples): the token all-gather is the only
+        collective of the call."""
         from . import dist as mdist
-        h = hashlib.sha256()
-        for ap1, ap2, tp in examples:
-            h.update(repr((str(ap1), str(ap2), str(tp))).encode())
-        mine = np.frombuffer(h.digest()[:8], dtype=np.int32).copy()
-        sig = np.concatenate([np.asarray([len(examples)], dtype=np.int32), mine])[None, :]          # [1, 3]
-        dev = self.model.tdev if dist.get_backend() == "nccl" else torch.device("cpu")
-        world = dist.get_world_size()
-        allsig, _ = mdist.gather_tokens(sig, np.zeros((1,), dtype=np.int32), world, 3, device=dev, per_rank=1)
-        if not (allsig == allsig[0]).all():
-            raise ValueError("data_parallel generate(): the ranks were given different `examples` "
-                             f"(counts {allsig[:, 0].tolist()}); call it with the same list on every rank, or turn sharding off")
+        mdist.agree_on_examples(mdist.examples_signature(examples))
 
     def _clamp_max_len(self, entry_length: int) -> int:
         limit = self.model.max_new_tokens_limit()

@@ -198,12 +198,14 @@ def late_case(args, model, prefix, t0):
     )
 
 
-B32_STEPS = 8
+B32_STEPS = 64                      # BASELINE configs[1]: max_len = 64 -- the whole benchmarked run is reference-pinned
+B32_LOGIT_STEPS = tuple(range(8)) + tuple(range(15, 64, 8))     # steps whose sub-vocabulary logits are stored
 
 
 def b32_case(args, model, t0):
-    """BASELINE configs[1]'s batch (the bench.py workload: examples 0..31) through the reference itself: 8 greedy steps of
-    all 32 rows, a sub-sample of every row's prefix, and every row's last-position logits (sub-vocabulary) of all steps."""
+    """BASELINE configs[1]'s batch (the bench.py workload: examples 0..31) through the reference itself: all 64 greedy steps
+    of all 32 rows (max_len = 64), a sub-sample of every row's prefix, every row's maximum logit and top-2 gap at every step,
+    and the last-position logits (sub-vocabulary) of steps 0..7, 15, 23, ..., 63."""
     a1, a2, ids = synth.make_batch(32)
     with torch.no_grad():
         prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
@@ -215,23 +217,49 @@ def b32_case(args, model, t0):
     top2 = torch.topk(L, 2, dim=-1).values
     gaps = (top2[..., 0] - top2[..., 1]).numpy()
     print(f"b32 tokens ({time.time() - t0:.1f}s): min top-2 gap {gaps.min():.4f}\n{toks}")
+    ls = np.asarray(B32_LOGIT_STEPS)
     np.savez_compressed(os.path.join(args.out, "b32.npz"), steps=B32_STEPS, tokens=toks, top2_gap=gaps,
-                        prefix_sub=prefix[:, ::7, ::5].numpy(), logits_sub=L[:, :, SUB_VOCAB].numpy(), sub_vocab=SUB_VOCAB,
-                        logits_max=L.max(-1).values.numpy())
+                        prefix_sub=prefix[:, ::7, ::5].numpy(), logit_steps=ls, logits_sub=L[ls][:, :, SUB_VOCAB].numpy(),
+                        sub_vocab=SUB_VOCAB, logits_max=L.max(-1).values.numpy())
+
+
+B64_STEPS = 16
+
+
+def cfg3_case(args, model, t0):
+    """BASELINE configs[3]'s shape through the REFERENCE itself: 2 examples of 2 x 30 s clips (960,000 samples -> 7 encoder
+    crops per clip, htsat.py:908-936), `generate_prefix_inference` + 16 steps of the unmodified `_generate_batch`."""
+    a1, a2, ids = synth.make_batch(CFG3_ROWS, n_samples=30 * spec.SAMPLE_RATE)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
+                                                        "input": {"input_ids": torch.from_numpy(ids)}})
+        _, toks, logits_log = ref_generate_tokens(model, prefix, CFG3_STEPS, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    L = torch.stack(logits_log)
+    top2 = torch.topk(L, 2, dim=-1).values
+    gaps = (top2[..., 0] - top2[..., 1]).numpy()
+    print(f"cfg3 (2 x 30 s) tokens ({time.time() - t0:.1f}s): min top-2 gap {gaps.min():.4f}\n{toks}")
+    np.savez_compressed(os.path.join(args.out, "cfg3.npz"), rows=CFG3_ROWS, steps=CFG3_STEPS, n_samples=30 * spec.SAMPLE_RATE,
+                        tokens=toks, top2_gap=gaps, prefix_sub=prefix[:, ::3, ::5].numpy(), sub_vocab=SUB_VOCAB,
+                        logits_sub=L[:, :, SUB_VOCAB].numpy(), logits_max=L.max(-1).values.numpy())
+
+
+CFG3_ROWS = 2
+CFG3_STEPS = 16
 
 
 def b64_tail_case(args, model, t0):
-    """examples 32..63 (the second half of the north_star's 64-example batch) through the reference: 4 greedy steps + prefix"""
+    """examples 32..63 (the second half of the north_star's 64-example batch) through the reference: 16 greedy steps + prefix"""
     a1, a2, ids = synth.make_batch(32, first=32)
     with torch.no_grad():
         prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
                                                         "input": {"input_ids": torch.from_numpy(ids)}})
-        _, toks, logits_log = ref_generate_tokens(model, prefix, 4, stop_id=-1)
+        _, toks, logits_log = ref_generate_tokens(model, prefix, B64_STEPS, stop_id=-1)
     toks = np.asarray(toks, dtype=np.int64)
     L = torch.stack(logits_log)
     top2 = torch.topk(L, 2, dim=-1).values
     print(f"b64 tail tokens ({time.time() - t0:.1f}s): min top-2 gap {float((top2[..., 0] - top2[..., 1]).min()):.4f}")
-    np.savez_compressed(os.path.join(args.out, "b64tail.npz"), first=32, steps=4, tokens=toks,
+    np.savez_compressed(os.path.join(args.out, "b64tail.npz"), first=32, steps=B64_STEPS, tokens=toks,
                         prefix_sub=prefix[:, ::13, ::9].numpy(), logits_max=L.max(-1).values.numpy())
 
 
@@ -370,7 +398,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64,example "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64,cfg3,example "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -469,6 +497,8 @@ def main():
         b32_case(args, model, t0)
     if "b64" in only or (not only and not args.skip_long):
         b64_tail_case(args, model, t0)
+    if "cfg3" in only or (not only and not args.skip_long):
+        cfg3_case(args, model, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
     if want("example"):

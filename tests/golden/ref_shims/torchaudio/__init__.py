@@ -1,7 +1,7 @@
 """Shim used only by tests/golden/make_golden.py (case "example"): the two calls the reference makes into torchaudio
 (wrapper.py:144-148).  `load` decodes 16-bit PCM WAV exactly like torchaudio.load(normalize=True) does (int16 / 32768 as
-float32, shape (channels, frames)); `transforms.Resample` is this build's restatement of torchaudio's default sinc-Hann
-resampler (mellow_amd/audio.py) -- PARITY UNPINNED at that boundary, see ../README.md."""
+float32, shape (channels, frames)); `transforms.Resample` is the independent fp64 oracle of torchaudio's published default
+sinc-Hann algorithm (oracle/resample_oracle.py; nothing of the product is imported), see ../README.md."""
 import wave
 
 import numpy as np

@@ -23,6 +23,19 @@ from mellow_amd import dist as mdist, synth
 from mellow_amd.engine import Engine
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+
+# every collective entry point of torch.distributed, counted: a data-parallel generate may make exactly ONE (north_star)
+_COLL = ("all_gather", "all_gather_into_tensor", "all_gather_object", "all_reduce", "broadcast", "broadcast_object_list", "gather",
+         "scatter", "reduce", "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "barrier", "send", "recv")
+_calls = []
+def _count(name, fn):
+    def w(*a, **k):
+        _calls.append(name)
+        return fn(*a, **k)
+    return w
+for _n in _COLL:
+    if hasattr(dist, _n):
+        setattr(dist, _n, _count(_n, getattr(dist, _n)))
 sd = synth.make_state_dict(0)
 eng = Engine(device=0)
 eng.load_state_dict(sd)
@@ -75,7 +88,9 @@ for i, (f, secs, sr) in enumerate(((440, 2.5, 44100), (1000, 10.0, 32000), (250,
 dist.barrier()
 examples = [[paths[0], paths[1], "compare the two"], [paths[1], paths[2], "which is higher"], [paths[2], paths[0], "describe"]]
 m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=True)
+del _calls[:]
 sharded = m.generate(examples=examples, max_len=6, top_p=0.8, temperature=1.0)
+assert _calls == ["all_gather"], _calls        # ONE collective per data-parallel generate: the token gather (the same-examples check uses the store)
 # sharding is opt-in and checked: ranks that hold DIFFERENT example lists are refused on every rank, nothing hangs
 try:
     m.generate(examples=examples[: 2 + rank], max_len=6, top_p=0.8, temperature=1.0)

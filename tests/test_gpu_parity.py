@@ -42,7 +42,7 @@ def engine(request, synth_sd):
 def engine_f32(synth_sd):
     """the exact-fp32 engine, for tests that compare another mode against it or are precision-independent"""
     from mellow_amd.engine import Engine
-    e = Engine(device=0)
+    e = Engine(device=0, precision="f32")
     e.load_state_dict(synth_sd)
     yield e
     e.close()
@@ -165,7 +165,7 @@ def test_stft_runs_as_fft_only_on_windowed_dft_weights(synth_sd):
         scale = float(p64[i].max())
         assert float((pw[i, :, :513] - p64[i]).abs().max()) <= 1e-6 * scale + 1e-30, i
     assert float(pw[1].abs().max()) == 0.0                                    # silence stays exactly zero
-    e0 = Engine(device=0)
+    e0 = Engine(device=0, precision="f32")
     e0.load_state_dict(synth_sd)
     assert not e0.stft_is_fft()
     sd = dict(synth_sd)
@@ -327,7 +327,7 @@ def test_large_batches_keep_every_row_and_stay_deterministic(engine, batch1024):
 
 @pytest.mark.parametrize("B,n_new", [(2, 90), (1, 1600)])
 def test_long_context_decode_matches_independent_prefill(engine, golden_dir, B, n_new):
-    """Contexts beyond one attention chunk (> 448 keys) up to the engine's 2048-key limit (389 + 1600 = 1989 keys: five key
+    """Contexts beyond one attention chunk (> 448 keys) up to 389 + 1600 = 1989 keys (five key
     chunks per split), checked against an independent implementation inside the engine: the prefill path (big GEMM + flash
     attention) run on the EXTENDED sequence must give the same last-position logits as the step-by-step KV-cached decode.
     (Up to 688 keys the decode is pinned against the reference itself: test_late_positions_match_reference.)"""
@@ -349,19 +349,73 @@ def test_long_context_decode_matches_independent_prefill(engine, golden_dir, B, 
     assert dec_logits.argmax(-1).tolist() == pre_logits.argmax(-1).tolist()
 
 
-def test_max_len_at_the_key_limit(engine_f32, batch2, golden_dir):
-    """max_len = everything the KV pages can hold (2048 - 389 = 1659 steps): runs to the end, starts with the golden tokens,
-    and a longer request is refused by the C ABI (the wrapper clamps with a warning instead: tests/test_tokenizer_cpu.py)."""
-    from mellow_amd.engine import EngineError
+def test_max_len_at_the_page_limit(synth_sd, batch2, golden_dir):
+    """max_len = everything the KV pages of an engine built with max_positions = 2048 can hold (2048 - 389 = 1659 steps): runs
+    to the end, starts with the golden tokens, and a longer request is refused by the C ABI (the wrapper clamps with a warning
+    instead: tests/test_tokenizer_cpu.py).  The default engine goes to the LM's own 8192 positions (next test)."""
+    from mellow_amd.engine import Engine, EngineError
     a1, a2, ids = batch2
-    L = engine_f32.max_new_tokens_limit()
-    assert L == 2048 - spec.PREFIX_LEN
-    toks, lens, n, _ = engine_f32.generate(a1[:1], a2[:1], ids[:1], max_len=L, stop_id=-1)
+    e2k = Engine(device=0, precision="f32", max_positions=2048)
+    e2k.load_state_dict(synth_sd)
+    try:
+        L = e2k.max_new_tokens_limit()
+        assert L == 2048 - spec.PREFIX_LEN
+        toks, lens, n, _ = e2k.generate(a1[:1], a2[:1], ids[:1], max_len=L, stop_id=-1)
+        g = np.load(os.path.join(golden_dir, "late.npz"))
+        assert n == L and toks.shape == (1, L) and np.array_equal(toks[0, :300], g["tokens"][0])
+        assert (toks >= 0).all() and (toks < 49152).all()
+        with pytest.raises(EngineError, match="exceeds max_positions 2048"):
+            e2k.generate(a1[:1], a2[:1], ids[:1], max_len=L + 1, stop_id=-1)
+    finally:
+        e2k.close()
+
+
+def test_max_len_3000_beyond_the_old_2048_key_cap(engine, golden_dir):
+    """the reference's loop is bounded only by the LM's 8192 positions (wrapper.py:216, decoder.py:25); the
+    engine's pages now grow with the request instead of clamping at 2048 keys.  One row, max_len = 3000 (contexts to 3389 keys,
+    seven 448-key chunks per split): (a) the first 300 tokens are the reference's own (late.npz); (b) the KV-cached decode at
+    the END of the run agrees with an independent implementation inside the engine -- the prefill path (big GEMMs + flash
+    attention) run on the whole extended sequence gives the same last-position logits and the same next token."""
+    assert engine.max_new_tokens_limit() == 8192 - spec.PREFIX_LEN
+    e = np.load(os.path.join(golden_dir, "enc10.npz"))
+    a1, a2, ids = synth.make_batch(1)
+    L = 3000
+    toks, lens, n, _ = engine.generate(a1, a2, ids, max_len=L, stop_id=-1)
     g = np.load(os.path.join(golden_dir, "late.npz"))
     assert n == L and toks.shape == (1, L) and np.array_equal(toks[0, :300], g["tokens"][0])
-    assert (toks >= 0).all() and (toks < 49152).all()
-    with pytest.raises(EngineError, match="2048-key"):
-        engine_f32.generate(a1[:1], a2[:1], ids[:1], max_len=L + 1, stop_id=-1)
+    prefix = torch.from_numpy(e["prefix"])[:1]
+    sd_embed = synth.make_state_dict(0)[spec.LM + "model.embed_tokens.weight"]
+    ext = torch.cat((prefix, sd_embed[torch.from_numpy(toks[:, : L - 1]).long()]), 1)       # (1, 389 + 2999, 576)
+    pre_logits = engine.lm_prefill(ext, reserve=2).cpu()
+    assert int(pre_logits.argmax(-1)) == int(toks[0, L - 1])
+    # and step by step over the last stretch: teacher-forced decode from a 3300-key prefill reaches the same logits
+    cut = 3300 - 389
+    logits = engine.lm_prefill(ext[:, : 389 + cut], reserve=L - cut + 2)
+    for i in range(cut, L - 1):
+        assert int(logits.argmax(-1)) == int(toks[0, i]), i
+        logits = engine.lm_decode_step(toks[:, i])
+    _close(logits.cpu(), pre_logits, rel=0, atol=3e-3, name="decode@3388 keys vs prefill of the extended sequence")
+
+
+def test_batches_beyond_1024_rows_run_as_passes(engine_f32, golden_dir):
+    """one pass of the engine takes 1024 rows; `mellow_generate` runs a larger batch as consecutive passes.
+    1030 rows under the reference stop rule: pass 0 (1024 rows cycling over examples that stop at steps 8 / 17 / 3 / never)
+    runs to max_len, pass 1 (six copies of the example that stops at step 3) ends early; every row's tokens and length are the
+    reference's (eos_mixed.npz), the columns pass 1 never computed are -1, the call reports the longest pass."""
+    g = np.load(os.path.join(golden_dir, "eos_mixed.npz"))
+    stop, L = int(g["stop_id"]), int(g["max_len"])
+    ex = g["one_never_examples"].tolist()                    # (1, 2, 4, 3): stop at 8, 17, 3, never
+    rows = [ex[i % 4] for i in range(1024)] + [ex[2]] * 6
+    a1, a2, ids = synth.make_examples(ex)
+    pick = [ex.index(r) for r in rows]
+    toks, lens, n, _ = engine_f32.generate(a1[pick], a2[pick], ids[pick], max_len=L, stop_id=stop)
+    assert toks.shape == (1030, L) and n == L
+    want = {ex[i]: g[f"one_never_row{i}"] for i in range(4)}
+    for r, e_ in enumerate(rows):
+        assert int(lens[r]) == len(want[e_]) and toks[r, : lens[r]].tolist() == want[e_].tolist(), r
+    assert (toks[1024:, 5:] == -1).all()                     # pass 1 stopped after step 3 (step 4 may still have been enqueued)
+    free = g["one_never_free_tokens"][3]
+    assert np.array_equal(toks[3, :L], free[:L])             # a row that never stops: the free-running reference tokens
 
 
 def test_late_positions_match_reference(engine, batch2, golden_dir):
@@ -445,9 +499,10 @@ def test_all_position_forward_matches_reference(engine, batch2, golden_dir):
 
 def test_batch32_matches_reference(engine, golden_dir):
     """BASELINE configs[1]'s batch -- the 32 examples `bench.py` times -- against the REFERENCE run on the same 32 examples
-    (tests/golden/b32.npz: unmodified `generate_prefix_inference` + `_generate_batch`, 8 steps; minimum top-2 gap 0.043):
-    every row's greedy tokens are equal, every row's prefix agrees, and the last-position logits of all 8 steps (teacher-forced
-    with the reference's tokens, so a late divergence cannot hide an early one) agree within the 3e-3 of the fp32 path."""
+    (tests/golden/b32.npz: unmodified `generate_prefix_inference` + `_generate_batch` for ALL 64 steps of max_len = 64 -- the
+    whole benchmarked run; minimum top-2 gap 0.0115): the 32 x 64 token matrix is equal, every row's prefix agrees, and
+    teacher-forced with the reference's tokens (so a late divergence cannot hide an early one) the maximum logit of every row
+    at every step and the sub-vocabulary logits of steps 0..7, 15, 23, ..., 63 agree within the 3e-3 of the fp32 path."""
     g = np.load(os.path.join(golden_dir, "b32.npz"))
     a1, a2, ids = synth.make_batch(32)
     steps = int(g["steps"])
@@ -457,11 +512,14 @@ def test_batch32_matches_reference(engine, golden_dir):
     pre = engine.prefix(a1, a2, ids)
     _close(pre[:, ::7, ::5], g["prefix_sub"], name="prefix of all 32 rows (sub-sampled)")
     sub = torch.from_numpy(g["sub_vocab"])
+    assert steps == 64 and g["tokens"].shape == (32, 64)
+    kept = {int(s): k for k, s in enumerate(g["logit_steps"])}
     logits = engine.lm_prefill(pre, reserve=steps)
     for i in range(steps):
         if i:
             logits = engine.lm_decode_step(g["tokens"][:, i - 1])
-        _close(logits[:, sub], g["logits_sub"][i], rel=0, atol=3e-3, name=f"logits of 32 rows at step {i}")
+        if i in kept:
+            _close(logits[:, sub], g["logits_sub"][kept[i]], rel=0, atol=3e-3, name=f"logits of 32 rows at step {i}")
         _close(logits.max(-1).values, g["logits_max"][i], rel=0, atol=3e-3, name=f"max logit at step {i}")
         assert logits.argmax(-1).cpu().tolist() == g["tokens"][:, i].tolist()
 
@@ -476,15 +534,16 @@ def test_rows_migrate_between_blocks_when_most_have_stopped(engine_f32, golden_d
     g = np.load(os.path.join(golden_dir, "b32.npz"))
     stop = 42274
     early = [4, 9, 14, 22, 24, 26]                   # first stop id at steps 3, 3, 3, 2, 6, 5
-    late = [0, 1, 3, 7, 8, 12]                       # no stop id within the golden's 8 steps
+    late = [0, 1, 3, 7, 8, 12]                       # no stop id within the first 8 steps
     rows = []
     for i in range(n_rows):                          # n_early early rows, then late ones, through all the blocks
         rows.append(early[(i // 8 * 5 + i % 8) % 6] if i % 8 < n_early else late[(i // 8 * 3 + i % 8) % 6])
     a1, a2, ids = synth.make_examples(rows)
-    L = int(g["steps"])
+    L = 8
     toks, lens, n, _ = engine_f32.generate(a1, a2, ids, max_len=L, stop_id=stop)
     assert engine_f32.last_row_repacks() >= min_repacks
-    ref = g["tokens"]
+    ref = g["tokens"][:, :L]
+    assert all(stop not in ref[e_] for e_ in late)
     for i, ex in enumerate(rows):
         want = ref[ex]
         hit = np.flatnonzero(want == stop)
@@ -498,8 +557,8 @@ def test_rows_migrate_between_blocks_when_most_have_stopped(engine_f32, golden_d
 
 def test_batch64_matches_reference(engine, golden_dir):
     """The north_star's batch of 64 in ONE call (two 32-row blocks): rows 0..31 against the reference's 32-example run
-    (b32.npz), rows 32..63 against its run of examples 32..63 (b64tail.npz) -- tokens equal, prefixes and the per-step maximum
-    logit (teacher-forced) within the fp32 path's tolerances."""
+    (b32.npz), rows 32..63 against its run of examples 32..63 (b64tail.npz, 16 steps) -- tokens equal, prefixes and the per-step
+    maximum logit (teacher-forced) within the fp32 path's tolerances."""
     g1 = np.load(os.path.join(golden_dir, "b32.npz"))
     g2 = np.load(os.path.join(golden_dir, "b64tail.npz"))
     a1, a2, ids = synth.make_batch(64)
@@ -577,6 +636,22 @@ def test_mixed_eos_matches_reference_cut_rule(engine, synth_sd, golden_dir):
     m.model.close()
 
 
+def test_wrapper_without_keywords_runs_the_benchmarked_mode(synth_sd, golden_dir, monkeypatch):
+    """`MellowWrapper("v0", "v0", 0)` with no precision keyword runs the mode bench.py's `dtype` names
+    (f32x3, the library's default), and that mode gives the reference's tokens."""
+    from mellow_amd import MellowWrapper
+    from mellow_amd.engine import DEFAULT_PRECISION, Engine
+    monkeypatch.delenv("MELLOW_PRECISION", raising=False)
+    m = MellowWrapper("v0", "v0", 0, state_dict=synth_sd, tokenizer=_IdTokenizer(-1))      # state_dict / tokenizer: offline stand-ins
+    assert m.model.precision == DEFAULT_PRECISION == "f32x3"
+    assert Engine.__init__.__defaults__[-1] is None
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    a1, a2, ids = synth.make_batch(2)
+    toks, *_ = m.model.generate(a1, a2, ids, max_len=int(g["steps"]), stop_id=-1)
+    assert np.array_equal(toks, g["tokens"])
+    m.model.close()
+
+
 def test_row_block_early_exit(engine, golden_dir):
     """B = 40 = two 32-row blocks under the reference stop rule: block 0 holds 32 copies of an example that produces the stop
     id at step 3, block 1 rows that stop at steps 8 / 17 / never.  After step 3 block 0 is no longer computed (its columns stay
@@ -621,6 +696,21 @@ def test_stop_at_first_token_and_nan_audio(engine, batch2, golden_dir):
     assert np.array_equal(toks, g["tokens"][:, :4])
     with pytest.raises(IndexError):
         engine.generate(a1, a2, np.full_like(ids, 49152), max_len=2)
+    # ids that are already device int32 (the timed path: no torch kernel, no host sync) are range-checked ON the device: the
+    # prefix kernel flags the call's error word, the C call fails with the reference's IndexError text, nothing is left behind
+    for bad_id in (49152, -3, 2 ** 31 - 1):
+        dev_ids = torch.from_numpy(ids).to(engine.tdev, torch.int32)
+        dev_ids[1, 5] = bad_id
+        with pytest.raises(IndexError, match="index out of range in self"):
+            engine.generate(a1, a2, dev_ids, max_len=2)
+        with pytest.raises(IndexError):
+            engine.prefix(a1, a2, dev_ids)
+    big = torch.from_numpy(ids).to(engine.tdev)                     # int64 on the device: 2^32 + 5 must not alias id 5
+    big[0, 0] = 2 ** 32 + 5
+    with pytest.raises(IndexError):
+        engine.generate(a1, a2, big, max_len=2)
+    toks, *_ = engine.generate(a1, a2, torch.from_numpy(ids).to(engine.tdev, torch.int32), max_len=4, stop_id=-1)
+    assert np.array_equal(toks, g["tokens"][:, :4])
 
 
 def test_max_len_values_share_one_graph_and_any_out_buffer(engine, batch2, golden_dir):
@@ -706,7 +796,7 @@ def test_wrapper_end_to_end_from_wav_files(synth_sd, tmp_path):
 def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
     """BASELINE configs[2] at its exact per-rank shape: 32 examples, top_p=0.8, temperature=1.0, max_len=300 (context 389..689).
     Rows 0 and 1 equal the REFERENCE's own 300-step run of those two examples (late.npz), all 32 rows equal the reference's
-    32-example run for its 8 steps (b32.npz); the sampling arguments change nothing (reference wrapper.py:220-232 never
+    32-example run for all of its 64 steps (b32.npz); the sampling arguments change nothing (reference wrapper.py:220-232 never
     removes the arg-max); a long run extends a short one."""
     a1, a2, ids = synth.make_batch(32)
     t300, lens, n, _ = engine.generate(a1, a2, ids, max_len=300, top_p=0.8, temperature=1.0, stop_id=0, ignore_stop=True)
@@ -751,7 +841,7 @@ def test_fused_and_five_launch_decode_layers_agree(engine_f32, synth_sd, monkeyp
     summation-order noise.  B = 2 for 40 steps, and B = 33 (two row blocks, the second with one row)."""
     from mellow_amd.engine import Engine
     monkeypatch.setenv("MELLOW_DECODE_FUSE", "0")
-    e5 = Engine(device=0)
+    e5 = Engine(device=0, precision="f32")
     e5.load_state_dict(synth_sd)
     monkeypatch.delenv("MELLOW_DECODE_FUSE")
     try:
@@ -801,7 +891,7 @@ def test_split_prefill_is_bit_identical_to_one_chain(synth_sd, monkeypatch):
 
 def test_fork_needs_a_loaded_engine_and_shares_its_answers(engine_f32):
     from mellow_amd.engine import Engine, EngineError
-    raw = Engine(device=0)
+    raw = Engine(device=0, precision="f32")
     with pytest.raises(EngineError, match="fork needs"):
         raw.fork()
     raw.close()
@@ -895,7 +985,7 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
         e8.load_state_dict(sd)
     finally:
         del os.environ["MELLOW_DECODE_FUSE"]
-    e32 = Engine(device=0)
+    e32 = Engine(device=0, precision="f32")
     e32.load_state_dict(sd)
     a1, a2, ids = synth.make_batch(3)
     pre = e32.prefix(a1, a2, ids)
@@ -910,7 +1000,7 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
         l32 = e32.lm_decode_step(tok)
         l8 = e8.lm_decode_step(tok)
     # and the quantisation is real: against the UN-quantised checkpoint the same engine differs at the percent level
-    e0 = Engine(device=0)
+    e0 = Engine(device=0, precision="f32")
     e0.load_state_dict(synth_sd)
     l0 = e0.lm_prefill(e0.prefix(a1, a2, ids), reserve=2)
     os.environ["MELLOW_FP8_PREFILL"] = "0"
@@ -1136,11 +1226,11 @@ def test_encoder_activations_beyond_4gib(engine):
         assert torch.equal(big[idx], alone[0]), idx
 
 
-def test_device_resampler_matches_host_twin_parity_unpinned(engine_f32):
-    """PARITY UNPINNED against torchaudio (absent offline): mellow_resample (A0 on the device) == mellow_amd.audio.resample
-    (the host restatement of torchaudio's sinc_interp_hann defaults): 44.1 kHz -> 32 kHz and 48 kHz -> 32 kHz, odd lengths,
-    two clips at once.  Tolerance: fp32 summation order of a 459-tap dot product.  The closed-form properties of the filter
-    (DC gain, in-band tone amplitude, stop-band rejection, output lengths) are checked in test_device_resampler_closed_form."""
+def test_device_resampler_matches_host_twin(engine_f32):
+    """mellow_resample (A0 on the device) == mellow_amd.audio.resample (the host form): 44.1 kHz -> 32 kHz and 48 kHz -> 32 kHz,
+    odd lengths, two clips at once.  Tolerance: fp32 summation order of a 459-tap dot product.  BOTH are checked against the
+    independent fp64 oracle (test_device_resampler_against_the_independent_fp64_oracle, tests/test_host_cpu.py); the closed-form
+    properties of the filter are checked in test_device_resampler_closed_form."""
     from mellow_amd import audio
     rng = np.random.default_rng(9)
     for sr, n in ((44100, 403604), (48000, 12345), (16000, 4000), (22050, 1)):
@@ -1149,6 +1239,29 @@ def test_device_resampler_matches_host_twin_parity_unpinned(engine_f32):
         got = engine_f32.resample(x, sr, 32000).cpu()
         assert got.shape == want.shape, (sr, n, got.shape, want.shape)
         assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (sr, n)
+
+
+def test_device_resampler_against_the_independent_fp64_oracle(engine_f32, golden_dir):
+    """f1 on the device: `mellow_resample` against oracle/resample_oracle.py (fp64 per-output-sample windowed-sinc sums of
+    torchaudio's published algorithm, shares nothing with the product) on the reference's own fixture clips (both edges of
+    resource/1.wav and 2.wav @ 44.1 kHz) and on 48 / 22.05 / 16 / 8 kHz noise.  Tolerance: the fp64-derived per-sample bound
+    (taps + 2) * 2^-24 * sum|x||h|, and 2e-6 of the peak."""
+    from oracle import resample_oracle as R
+    g = np.load(os.path.join(golden_dir, "example.npz"))
+    cases = []
+    for k in ("pcm1", "pcm2"):
+        w = g[k].astype(np.float32) / 32768.0
+        cases += [(k + "_head", 44100, w[None, :60000]), (k + "_tail", 44100, w[None, -45000:])]
+    rng = np.random.default_rng(9)
+    for sr, n in ((48000, 12345), (22050, 7777), (16000, 4000), (22050, 1), (8000, 333)):
+        cases.append((f"noise_{sr}_{n}", sr, (rng.standard_normal((2, n)) * 0.3).astype(np.float32)))
+    for name, sr, x in cases:
+        want, bound = R.resample(x, sr, 32000, return_bound=True)
+        got = engine_f32.resample(torch.from_numpy(x), sr, 32000).cpu().numpy().astype(np.float64)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        d = np.abs(got - want)
+        assert (d <= R.fp32_tolerance(bound, sr, 32000)).all(), (name, float(d.max()))
+        assert d.max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (name, float(d.max()))
 
 
 def test_device_resampler_closed_form(engine_f32):

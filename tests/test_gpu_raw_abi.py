@@ -23,7 +23,7 @@ class Cfg(C.Structure):                      # mellow_config_t
 
 
 @pytest.mark.parametrize("host_rope", [True, False], ids=["rope_from_torch", "rope_in_library"])
-@pytest.mark.parametrize("precision", [0, 2], ids=["f32", "f32x3"])
+@pytest.mark.parametrize("precision", [0, 2, None], ids=["f32", "f32x3", "library_default"])
 def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope, precision):
     lib = C.CDLL(LIB)
     lib.mellow_last_error.restype = C.c_char_p
@@ -37,7 +37,8 @@ def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope,
     cfg = Cfg(2, 49152, 576, 1536, 30, 9, 3, 64, 1e-5, 100000.0, 2048, 129, 389, 0)
     h = C.c_void_p()
     chk(lib.mellow_engine_create(C.byref(cfg), device, C.byref(h)))
-    chk(lib.mellow_engine_set_precision(h, precision))                     # section 6
+    if precision is not None:                                               # no call: the library's default mode (f32x3)
+        chk(lib.mellow_engine_set_precision(h, precision))                 # section 6
     state = synth.make_state_dict(0)                                        # stands for torch.load(self.model_path)
     for key, t in state.items():
         t = t.contiguous()

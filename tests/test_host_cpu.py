@@ -79,8 +79,10 @@ def test_host_ingest_against_the_reference_preprocess_audio_goldens():
     """A0 on the committed fixture PCM (tests/golden/example.npz: resource/1.wav, 2.wav decoded to int16 -- data -- and the
     arrays the REFERENCE's own preprocess_audio returned for them, generated in the build container): the tile case
     403,604 @ 44.1 kHz -> 292,865 -> repeated to 320,000, and the crop case 445,940 -> 323,585 cut at the offset the reference
-    drew from `random` under the stored seed.  The resampling step inside both sides is this build's restatement of torchaudio's
-    (PARITY UNPINNED there: torchaudio is not installed); decode, flatten, tile, crop and the draw are pinned to the reference."""
+    drew from `random` under the stored seed.  The resampling step of the golden run was the independent fp64 oracle of
+    torchaudio's published algorithm (oracle/resample_oracle.py via tests/golden/ref_shims; torchaudio's binary is absent), so
+    the product's fp32 resampler is compared with something it shares no code with; decode, flatten, tile, crop and the draw
+    are pinned to the reference's own code."""
     import random
     g = np.load(os.path.join(ROOT, "tests", "golden", "example.npz"))
     assert int(g["sr1"]) == 44100 and g["pcm1"].shape == (403604,) and g["pcm2"].shape == (445940,) and g["pcm1"].dtype == np.int16
@@ -143,6 +145,19 @@ sys.path.insert(0, sys.argv[1])
 from mellow_amd import dist as mdist
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+
+# every collective entry point of torch.distributed, counted: a data-parallel generate may make exactly ONE (north_star)
+_COLL = ("all_gather", "all_gather_into_tensor", "all_gather_object", "all_reduce", "broadcast", "broadcast_object_list", "gather",
+         "scatter", "reduce", "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "barrier", "send", "recv")
+_calls = []
+def _count(name, fn):
+    def w(*a, **k):
+        _calls.append(name)
+        return fn(*a, **k)
+    return w
+for _n in _COLL:
+    if hasattr(dist, _n):
+        setattr(dist, _n, _count(_n, getattr(dist, _n)))
 n, L = 5, 7
 def fake_generate(a1, a2, ids, max_len, **kw):
     # token = 100*example + step; ragged step counts per shard, like early-stopping shards
@@ -157,6 +172,29 @@ for i in range(n):
     steps = L - owner
     assert toks[i, :steps].tolist() == (100 * i + np.arange(steps)).tolist(), (rank, i, toks[i])
     assert (toks[i, steps:] == -1).all() and lens[i] == steps - 1
+assert _calls == ["all_gather"], _calls                 # the gather is ONE collective
+# the cross-rank check of the opt-in sharding (wrapper._check_same_examples) goes through the rendezvous store: no collective
+del _calls[:]
+same = [["a.wav", "b.wav", "compare"], ["c.wav", "d.wav", "describe"]]
+mdist.agree_on_examples(mdist.examples_signature(same))
+for bad in (same[: 1 + rank],                                            # different COUNT per rank
+            [["a.wav", "b.wav", "compare"], ["c.wav", "d.wav", "describe" + "!" * rank]]):      # same count, different content
+    try:
+        mdist.agree_on_examples(mdist.examples_signature(bad))
+        raise SystemExit("mismatching example lists were accepted")
+    except ValueError as e:
+        assert "different `examples`" in str(e), e
+# in-memory audio is hashed by content: two long clips whose str() is the same summarised text must not collide
+x = np.zeros(5000, np.float32); y = x.copy(); y[2500] = 0.25
+assert str(x) == str(y) and mdist.examples_signature([[x, x, "p"]]) != mdist.examples_signature([[y, x, "p"]])
+assert mdist.examples_signature([[torch.from_numpy(y), x, "p"]]) == mdist.examples_signature([[y, x, "p"]])
+try:
+    mdist.agree_on_examples(mdist.examples_signature([[x if rank == 0 else y, x, "p"]]))
+    raise SystemExit("different clips with the same printed form were accepted")
+except ValueError:
+    pass
+mdist.agree_on_examples(mdist.examples_signature(same))       # and the sequence stays in step after refusals
+assert _calls == [], _calls
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -181,8 +219,27 @@ def test_bench_cli_contract_flags():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--inflight", "--no-cpu-baseline"):
+    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--inflight", "--no-cpu-baseline", "--preset", "configs3", "--clip-seconds"):
         assert flag in r.stdout
+
+
+def test_one_default_numeric_mode_everywhere():
+    """the mode a user gets with no keyword is the mode the bench line's `dtype` names -- f32x3 in the C
+    library's header, the ctypes `Engine`, `MellowWrapper` and bench.py alike (the GPU twin:
+    test_gpu_parity.py::test_wrapper_without_keywords_runs_the_benchmarked_mode)."""
+    import inspect
+    import re
+    from mellow_amd import engine as E, wrapper as W
+    assert E.DEFAULT_PRECISION == "f32x3"
+    assert inspect.signature(E.Engine.__init__).parameters["precision"].default is None        # None -> MELLOW_PRECISION or the default
+    assert inspect.signature(W.MellowWrapper.__init__).parameters["precision"].default is None
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r'add_argument\("--precision", choices=\([^)]*\), default="(\w+)"', bench)
+    assert m and m.group(1) == E.DEFAULT_PRECISION
+    hdr = open(os.path.join(ROOT, "include", "mellow_hip.h")).read()
+    assert "MELLOW_PRECISION_F32X3 (DEFAULT" in hdr and "experimental" not in hdr
+    src = open(os.path.join(ROOT, "mellow_amd", "csrc", "engine.cpp")).read()
+    assert "return mellow_engine_set_precision(e, MELLOW_PRECISION_F32X3);" in src              # mellow_engine_create
 
 
 def test_reference_import_name_is_a_drop_in():
@@ -198,6 +255,63 @@ def test_reference_import_name_is_a_drop_in():
         assert os.path.dirname(m.__file__) == os.path.join(ROOT, "mellow")
     finally:
         sys.path.remove(ROOT)
+
+
+RESAMPLE_CASES = ((48000, 12345), (22050, 7777), (16000, 4000), (22050, 1), (8000, 333))
+
+
+def _oracle_cases():
+    """(name, sample rate, float32 rows) the resampler checks run on: the reference's own fixture clips (resource/1.wav,
+    2.wav: 403,604 and 445,940 samples @ 44.1 kHz, the first 60,000 and the last 45,000 samples of each -- both edges of the
+    zero extension) and seeded noise at 48 / 22.05 / 16 / 8 kHz with odd lengths."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "example.npz"))
+    out = []
+    for k in ("pcm1", "pcm2"):
+        w = g[k].astype(np.float32) / 32768.0
+        out.append((k + "_head", 44100, w[None, :60000]))
+        out.append((k + "_tail", 44100, w[None, -45000:]))
+    rng = np.random.default_rng(9)
+    for sr, n in RESAMPLE_CASES:
+        out.append((f"noise_{sr}_{n}", sr, (rng.standard_normal((2, n)) * 0.3).astype(np.float32)))
+    return out
+
+
+def test_host_resampler_against_the_independent_fp64_oracle():
+    """f1 / A0's filter step (reference wrapper.py:144-148, torchaudio.transforms.Resample): `mellow_amd.audio.resample` (fp32
+    polyphase bank through conv1d) against oracle/resample_oracle.py (fp64, one windowed-sinc sum per output sample, nothing
+    shared with the product).  Tolerance = the fp64-derived bound of the oracle -- (taps + 2) * 2^-24 * sum|x||h| per sample,
+    what ANY fp32 evaluation of the same sums can differ by -- and, tighter, 1e-6 of the clip's peak (measured: 2-3e-7)."""
+    from oracle import resample_oracle as R
+    assert "mellow_amd" not in open(R.__file__).read().split('"""', 2)[2]          # the oracle's code imports nothing of the product
+    for name, sr, x in _oracle_cases():
+        want, bound = R.resample(x, sr, 32000, return_bound=True)
+        got = audio.resample(torch.from_numpy(x), sr, 32000).numpy().astype(np.float64)
+        assert got.shape == want.shape == (x.shape[0], R.output_length(x.shape[1], sr, 32000)), name
+        d = np.abs(got - want)
+        assert (d <= R.fp32_tolerance(bound, sr, 32000)).all(), (name, float(d.max()))
+        assert d.max() <= 1e-6 * max(1.0, float(np.abs(want).max())), (name, float(d.max()))
+
+
+def test_resample_oracle_whole_fixture_lengths_and_geometry():
+    """the oracle itself: torchaudio's geometry for the reference's fixtures (441 -> 320 after the gcd, width 9, 459 taps; output
+    lengths 292,865 and 323,585), the tile of the whole resource/1.wav the reference feeds the model, and closed-form checks
+    the product never sees (DC gain, a 1 kHz tone) so that product and oracle cannot be wrong together unnoticed."""
+    from oracle import resample_oracle as R
+    assert R.geometry(44100, 32000) == (441, 320, 316.8, 9, 459)
+    assert R.output_length(403604, 44100, 32000) == 292865 and R.output_length(445940, 44100, 32000) == 323585
+    assert R.geometry(16000, 32000)[:2] == (1, 2) and R.geometry(48000, 32000)[:2] == (3, 2)
+    n = 22050
+    dc = R.resample(np.full((1, n), 0.5), 44100, 32000)[0]
+    assert np.abs(dc[200:-200] - 0.5).max() < 1e-3
+    t = np.arange(n) / 44100.0
+    y = R.resample(np.sin(2 * np.pi * 1000.0 * t)[None], 44100, 32000)[0]
+    ref = np.sin(2 * np.pi * 1000.0 * np.arange(len(y)) / 32000.0)
+    assert np.abs(y[500:-500] - ref[500:-500]).max() < 1e-3
+    g = np.load(os.path.join(ROOT, "tests", "golden", "example.npz"))
+    w1 = g["pcm1"].astype(np.float32) / 32768.0
+    full = R.resample(w1[None], 44100, 32000)[0].astype(np.float32)                # what the shimmed reference resampled
+    tiled = np.concatenate([full, full])[:320000]
+    assert np.array_equal(tiled[::61], g["audio1_sub"])                             # the golden's audio1 IS the oracle's output, tiled
 
 
 def test_resampler_closed_form_properties():
