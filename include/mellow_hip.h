@@ -68,7 +68,10 @@ void mellow_engine_destroy(mellow_engine_t* e);
 /* A second execution context on the same device that SHARES a finalized engine's weights (no copy): its own HIP stream,
  * workspaces, KV pages and captured graphs.  Calls on `parent` and on the fork may overlap from different host threads (a
  * serving front-end pipelines independent batches this way: mellow_amd/serve.py); each handle is still serialised by its
- * caller.  Destroy every fork before its parent.  The reference has no counterpart (one synchronous model object). */
+ * caller.  Destroy every fork before its parent.  mellow_engine_fork / the fork's mellow_engine_destroy touch the PARENT (its
+ * fork count; while it has forks the parent runs its LM prefill as one chain instead of two half-batches on two streams, and it
+ * goes back to the split form when its last fork is destroyed): do not call them while a call is running on the parent.
+ * On failure nothing is leaked.  The reference has no counterpart (one synchronous model object). */
 int  mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out);
 
 /* Hand one checkpoint tensor to the engine under its reference state_dict key, e.g.

@@ -123,6 +123,18 @@ __device__ __forceinline__ void st_out(float4* p, float4 v) {
     *p = v;
 #endif
 }
+// A field of the by-value argument struct that only the EPILOGUE needs is otherwise fetched by a scalar load right where it is
+// used -- after the reduction barrier, followed at once by s_waitcnt lgkmcnt(0): a cold scalar-cache miss (the argument block's
+// lines beyond the preloaded dwords) on the critical tail of every launch, sometimes two in a row.  Naming the value in an empty
+// asm right after the kernel's vector loads have been ISSUED makes the compiler fetch it there, where the wait hides behind the
+// loads that are in flight anyway.  MEASURED (round 4, same box, tools/ab_run.sh): 46.89 ms of decode per 63 steps with the hoist
+// against 46.83 without (B = 64: 68.7 against 68.35) -- those scalar loads hit the scalar cache and cost nothing where they are;
+// the wait in front of the load block costs a little.  Off; -DMELLOW_HOIST_ON keeps the A/B.
+#ifdef MELLOW_HOIST_ON
+#define MELLOW_HOIST(x) asm volatile("" ::"s"(x))
+#else
+#define MELLOW_HOIST(x) ((void)0)
+#endif
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4ssq(float4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float4 w, float4 x) {
@@ -182,6 +194,8 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __res
 #pragma unroll
             for (int s = 0; s < KCD; ++s) sl[i][s] = sb[(int64_t)s * a.slabF_stride4 + i * 64];
         }
+        MELLOW_HOIST(a.pq); MELLOW_HOIST(a.rows); MELLOW_HOIST(a.ssq1); MELLOW_HOIST(a.xnewR);
+        if (W8) MELLOW_HOIST(wscale);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
@@ -367,6 +381,8 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     };
 #pragma unroll
     for (int u = 0; u < DA_G1; ++u) load_group(u);
+    MELLOW_HOIST(a.attF16); MELLOW_HOIST(a.att_ml); MELLOW_HOIST(a.RB); MELLOW_HOIST(a.eps);
+    if (FUSED) MELLOW_HOIST(a.xnewR);
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 1, dbg);
 
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // one chunk = the DA_G key groups a wave holds in registers (masked by weight, exp(-inf) = 0: slots beyond the context hold
-    // finite values, engine.cpp clear_page_tails; the 16 dim-quads of a key are one DPP row).  The first chunk (every context
+    // finite values, engine_lm.cpp clear_page_tails; the 16 dim-quads of a key are one DPP row).  The first chunk (every context
     // up to 448 keys per split) works on the registers loaded above; further chunks (longer contexts) reload and repeat.
     // Two code shapes around the same body (a macro, so that both are the literal source text):
     //   ONE   the plain loop; the compiler keeps a second set of K/V registers alive across the back edge (220 VGPRs)
@@ -662,6 +678,8 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
             }
         }
     }
+    MELLOW_HOIST(a.xmidF); MELLOW_HOIST(a.xmidF16); MELLOW_HOIST(a.ssq);
+    if (W8) MELLOW_HOIST(wscale);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -761,6 +779,8 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
         else w[i] = ldw<W8 != 0>(Wp, wslot + i * 64);
         x[i] = xp[i * 64];
     }
+    MELLOW_HOIST(a.logits); MELLOW_HOIST(a.cand_val); MELLOW_HOIST(a.cand_idx); MELLOW_HOIST(N);
+    if (W8) MELLOW_HOIST(wscale);
     __builtin_amdgcn_sched_barrier(0);
     kstamp(dslot, 1, dbg);
     f32x16 acc;
@@ -826,7 +846,7 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
                 const int oi = reinterpret_cast<int*>(red)[256 + tid + 32 * q];
                 if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
             }
-            const int64_t o = ((int64_t)rb * 32 + tid) * gridDim.x + nt;
+            const int64_t o = ((int64_t)rb * 32 + tid) * (N >> 5) + nt;          // N / 32 = gridDim.x (a dispatch-packet read in the tail otherwise)
             a.cand_val[o] = best;
             a.cand_idx[o] = idx;
         }
@@ -872,6 +892,8 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const float
 #pragma unroll
         for (int j = 0; j < 9; ++j) s4[j] = sq[j];
     }
+    MELLOW_HOIST(a.eps); MELLOW_HOIST(a.guF);
+    if (W8) MELLOW_HOIST(wscale);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (W8 == 2) {
@@ -967,6 +989,8 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const float* __
         else w[i] = ldw<W8 != 0>(Wp, wslot + i * 64);
         h4[i] = hp[i * 64];
     }
+    MELLOW_HOIST(a.dslabF); MELLOW_HOIST(a.slabF_stride4);
+    if (W8) MELLOW_HOIST(wscale);
     __builtin_amdgcn_sched_barrier(0);
     kstamp(4, 1, dbg);
     f32x16 acc;
@@ -1016,7 +1040,7 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const float* __
 // ----------------------------------------------------------------------------------------------------
 // K5+K1  the down projection of layer l and the q/k/v projection of layer l+1 in ONE launch (no kernel boundary between them).
 //     qkv_{l+1} = W' x_new with x_new = x_mid + Wd h is linear in (x_mid, h):  W' x_mid + (W' Wd) h.  The product Q = W' Wd
-//     (960 x 1536) is formed once at load time in fp64 and rounded to fp32 (engine.cpp), and stored behind W' in one P-layout
+//     (960 x 1536) is formed once at load time in fp64 and rounded to fp32 (engine_weights.cpp), and stored behind W' in one P-layout
 //     matrix Wq2 [30 n-tiles][72 + 192 k-tiles].  The residual stream itself still goes through Wd (the "side" tiles), so the
 //     composed weights only ever feed the next RMS-scaled projection, never the residual.
 //     Workgroup types (grid.x):   [0, 60)              x part: n-tile b % 30, k-chunk b / 30 (2 chunks of 36 k-tiles of x_mid)
@@ -1062,6 +1086,8 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
             else w[i] = ldw<W8 != 0>(Wx, wslot + i * 64);
             x[i] = xb[i * 64];
         }
+        MELLOW_HOIST(a.pq); MELLOW_HOIST(a.rows);
+        if (W8) MELLOW_HOIST(sc_x);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (W8 == 2) {
             float am = 0.f, inv, sc;
@@ -1096,6 +1122,8 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
             else w[i] = ldw<W8 != 0>(wbase, wslot + i * 64);
             h4[i] = hp[i * 64];
         }
+        MELLOW_HOIST(a.pq); MELLOW_HOIST(a.rows); MELLOW_HOIST(a.dslabF); MELLOW_HOIST(a.slabF_stride4);
+        if (W8) MELLOW_HOIST(wsc);
         __builtin_amdgcn_sched_barrier(0);
         kstamp(7, 1, dbg);
         if constexpr (W8 == 2) {

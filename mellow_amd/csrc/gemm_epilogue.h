@@ -17,6 +17,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     for (int mi = 0; mi < 2; ++mi) {
         const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
         if (m >= g.M) continue;
+        if (g.rs_ssq) {
+            // RMSNorm folded into this GEMM: the norm weight sits in the weight columns, the row statistic comes from the
+            // producer's per-64-column partial sums (fixed order), and (x W'^T) r = (x r) W'^T up to fp32 rounding
+            const float* sp = g.rs_ssq + (int64_t)m * g.rs_parts;
+            float ss = 0.f;
+            for (int p = 0; p < g.rs_parts; ++p) ss += sp[p];
+            const float r = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ni][mi][q] *= r;
+        }
         if constexpr (EPI == EPI_LINEAR) {
             int64_t crow = m;
             if (g.crow_map) crow = (int64_t)(m / g.rows_in) * g.rows_out + g.crow_map[m % g.rows_in];
@@ -45,6 +57,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
                     }
                     *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (g.C3) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ni][mi][4 * gq + j] = v[j];          // kept for the split store below
+                    }
+                }
+            }
+            if (g.C3) {
+                // the stored row, pre-split for the next x3q GEMM, and its sum of squares over this wave's 64 columns
+                const int P = pn * WN + wn;
+                if (P * 64 < g.N) {            // wave-uniform (N is a multiple of 64 on this path)
+                    float ss = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            float X[4], Y[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                X[j] = acc[ni][mi][8 * gp + j];
+                                Y[j] = acc[ni][mi][8 * gp + 4 + j];
+                                ss += X[j] * X[j] + Y[j] * Y[j];
+                            }
+                            apb_store_quads(reinterpret_cast<i32x4*>(g.C3), m, P * 8 + ni * 4 + 2 * gp, g.N >> 4, X, Y, h);
+                        }
+                    ss = half_sum(ss);                    // the two half-waves hold the two column halves of the row
+                    if (h == 0 && g.ssq_out) g.ssq_out[(int64_t)m * g.ssq_parts + P] = ss;
                 }
             }
         } else {

@@ -58,8 +58,19 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
-    // EPI_SWIGLU only: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C
+    // EPI_SWIGLU: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C.
+    // EPI_LINEAR (round 4, norm-free chaining of the f32x3 LM prefill): when set, the stored value (accumulator + bias +
+    // residual) is written to C AND pre-split to C3, and ssq_out[m * ssq_parts + P] receives its sum of squares over the
+    // 64-column group P = column / 64 -- the RMS statistic of the NEXT normalisation, which the consuming GEMM applies as a row
+    // scale of its accumulators (rs_*), the norm weight being folded into that GEMM's weight columns at load time.
     void* C3 = nullptr;
+    float* ssq_out = nullptr;
+    int ssq_parts = 0;
+    // consumer side: every accumulator of row m is multiplied by 1 / sqrt(sum_p rs_ssq[m * rs_parts + p] / rs_dim + rs_eps)
+    // before the epilogue arithmetic (RoPE / SwiGLU / store)
+    const float* rs_ssq = nullptr;
+    int rs_parts = 0;
+    float rs_dim = 1.f, rs_eps = 0.f;
     // fp8 mode (gemm_fp8.hip): both operands e4m3, fp32 accumulate, C = (A8 . W8^T) * a_scale[m] * w_scale[n] (+epilogue)
     const uint8_t* A8 = nullptr;      // row-major [M][lda8] bytes, lda8 = K rounded up to 64
     int64_t lda8 = 0;

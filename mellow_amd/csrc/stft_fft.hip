@@ -1,7 +1,7 @@
 // A1 as what it algorithmically is: a 1024-point FFT per frame (SURVEY.md 8d prices the STFT at 0.051 GFLOP per clip; the DFT
 // GEMM spends 2.10).  Reference: torchlibrosa Spectrogram(power=2) at htsat.py:647-649, called :864 -- two conv1d with the
 // windowed DFT basis, re^2 + im^2.  The engine takes this path only in f32x3 mode and only when the checkpoint's conv weights
-// ARE window[n] * cos / sin(2 pi k n / 1024) (verified element by element at load time, engine.cpp); otherwise the GEMM runs.
+// ARE window[n] * cos / sin(2 pi k n / 1024) (verified element by element at load time, engine_weights.cpp); otherwise the GEMM runs.
 //
 // One wave per frame, n = 64 a + b, k = k1 + 16 e + 256 f:
 //   A  lane b:           16-point DFT over a of window * x                       -> Y[b][k1],  times W_1024^(b k1)

@@ -8,7 +8,7 @@ name=$1; flags=$2
 mkdir -p mellow_amd/lib/ab
 out=mellow_amd/lib/ab/libmellow_hip_$name.so
 tmp=$(mktemp -d)
-for f in gemm_f32.hip gemm_fp8.hip gemm_bf16x3.hip decode.hip prefill_attn.hip encoder.hip stft_fft.hip engine.cpp; do
+for f in gemm_f32.hip gemm_fp8.hip gemm_bf16x3.hip decode.hip prefill_attn.hip encoder.hip stft_fft.hip engine.cpp engine_weights.cpp engine_encoder.cpp engine_lm.cpp engine_dev.cpp; do
   extra=""
   case $f in gemm_bf16x3.hip|gemm_fp8.hip|prefill_attn.hip|encoder.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";;
             decode.hip) extra="-mllvm -amdgpu-kernarg-preload-count=14";; esac     # the per-file flags of build.py

@@ -1,8 +1,8 @@
-# Everything under profiles/r03_* in one GPU call (gpurun -- bash tools/collect_profiles.sh).  PMC passes run alone
+# Everything under profiles/r04_* in one GPU call (gpurun -- bash tools/collect_profiles.sh).  PMC passes run alone
 # (--pmc only, no trace domains); FETCH_SIZE and WRITE_SIZE in separate passes.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r03
+R=r04
 O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 # --- PMC: HBM-side traffic of the GEMM family (per launch) and of the decode step (per step) ---
@@ -27,15 +27,20 @@ cp $O/pmc_decode_traffic.json profiles/${R}_pmc_decode_traffic.json
 unset MELLOW_PREFILL_SPLIT
 # --- bench lines ---
 timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-timeout 300 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_f32.json 2>/dev/null
+timeout 300 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > $O/bench_f32.json 2>/dev/null
 timeout 300 python bench.py --steps 5 --warmup 2 --precision fp8 --no-cpu-baseline > $O/bench_fp8.json 2>/dev/null
-timeout 300 python bench.py --steps 3 --warmup 1 --preset configs2 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_configs2.json 2>/dev/null
-timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_configs4.json 2>/dev/null
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs2 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > $O/bench_configs2.json 2>/dev/null
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > $O/bench_configs4.json 2>/dev/null
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs3 --no-cpu-baseline > $O/bench_configs3.json 2>/dev/null
 # --- kernel trace + stats of the default command, decode timeline ---
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 --inflight 0 > $O/bench_under_rocprofv3.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > $O/bench_under_rocprofv3.json 2>/dev/null
 cp $O/stats/st_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || find $O/stats -name "*stats*.csv" | head
+# the same with the prefill as ONE chain (MELLOW_PREFILL_SPLIT=1): kernel durations do not overlap, so the GEMM family time of
+# `roofline_gemm` can be re-derived from this file alone
+MELLOW_PREFILL_SPLIT=1 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats1 -o st --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > $O/bench_onechain_under_rocprofv3.json 2>/dev/null
+cp $O/stats1/st_kernel_stats.csv $O/bench_onechain_kernel_stats.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
 python tools/trace_summary.py $O/trace_dec/tr_kernel_trace.csv 40 > $O/decode_step_timeline.txt 2>&1
 timeout 400 python tools/fp8_agreement.py structured 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement.txt
-rm -rf $O/stats $O/pf $O/pw $O/df $O/dw $O/pm $O/trace_dec
+rm -rf $O/stats $O/stats1 $O/pf $O/pw $O/df $O/dw $O/pm $O/trace_dec
 ls -la $O

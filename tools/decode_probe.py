@@ -15,8 +15,10 @@ eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"))
 eng.load_state_dict(synth.make_state_dict(0))
 a1, a2, ids = synth.make_batch(B)
 a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
-dec = []
+dec, enc, pre = [], [], []
 for _ in range(4):
     toks, *_ = eng.generate(a1d, a2d, idsd, max_len=L, stop_id=0, ignore_stop=True)
-    dec.append(eng.last_phase_ms()["decode_ms"])
-print("decode_ms per pass", [round(d, 2) for d in dec], " ms/step", round(min(dec) / (L - 1), 4), " tokens[0,:6]", toks[0, :6].tolist())
+    ph = eng.last_phase_ms()
+    dec.append(ph["decode_ms"]); enc.append(ph["encode_ms"]); pre.append(ph["prefill_ms"])
+print("decode_ms per pass", [round(d, 2) for d in dec], " ms/step", round(min(dec) / (L - 1), 4), " tokens[0,:6]", toks[0, :6].tolist(),
+      " encode_ms", round(min(enc), 2), " prefill_ms", round(min(pre), 2))
