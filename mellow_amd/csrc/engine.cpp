@@ -241,6 +241,7 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (const char* pp = getenv("MELLOW_PREFILL_SPLIT")) e->prefill_parts = atoi(pp);
     if (const char* fn = getenv("MELLOW_PREFILL_FUSE_NORM")) e->prefill_fuse_norm = fn[0] != '0';
+    if (const char* fr = getenv("MELLOW_DECODE_FUSE_MAX_RB")) e->dec_fuse_max_rb = atoi(fr);
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));      // (streams: on first use)
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
@@ -411,7 +412,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     HIPCHK(hipStreamSynchronize(parent->stream));
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
-    c->prefill_fuse_norm = parent->prefill_fuse_norm;
+    c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb;
     c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;

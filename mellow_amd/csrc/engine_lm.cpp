@@ -272,7 +272,13 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
         float* vc = e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         // fused_in: this layer's q/k/v slabs (and the down slabs of x_new) were written by the previous layer's dec_qkv2 launch
-        const bool fused_in = l > l_begin && (w.qkv2 != nullptr || w.q2h8 != nullptr) && !same_w;
+        // The fused launch pays at ONE row block (B <= 32: 46.8 ms per 63 steps against 49.9 with the five-launch layer) and loses
+        // beyond (fp32 weights, same box: B = 64: 68.4 ms fused against 68.0, B = 96: 91.2 / 87.9, B = 128: 105.6 / 102.1,
+        // B = 256: 190.3 / 175.7, B = 512: 346.6 / 319.2 -- its composed operand is 1.7x the bytes of the two matrices it
+        // replaces, and a larger batch is bound by bytes, not by launches); the e4m3 form was measured ahead at four row blocks
+        // (round 3) and stays fused.  MELLOW_DECODE_FUSE_MAX_RB: developer override.
+        const bool fuse_rb = e->da.RB <= e->dec_fuse_max_rb;
+        const bool fused_in = l > l_begin && ((w.qkv2 != nullptr && fuse_rb) || w.q2h8 != nullptr) && !same_w;
         DecArgs a = e->da;
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
         a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
@@ -292,7 +298,7 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
           if (w.gu8) launch_dec_gateup(e->da, w.gu8, s, w.gu_sc);
           else launch_dec_gateup(e->da, w.gu16, s); }
         const LMLayerW* nx = (l + 1 < l_end && !same_w) ? &e->layers[l + 1] : nullptr;
-        if (nx && (nx->qkv2 || nx->q2h8)) {
+        if (nx && ((nx->qkv2 && fuse_rb) || nx->q2h8)) {
             // the down projection of this layer and the q/k/v projection of the next one as one launch (decode.hip, dec_qkv2_kernel)
             if (!(skip & 16))
             { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * (nx->q2h8 ? 1 : 4));

@@ -25,9 +25,22 @@ class EnginePool:
     """`n_contexts` engines on one device; `generate_many` pipelines a list of batches over them."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_contexts: int = 2, device: int = 0,
-                 max_positions: Optional[int] = None, lm: Optional[LMConfig] = None, precision: str = "f32"):
+                 max_positions: Optional[int] = None, lm: Optional[LMConfig] = None, precision: Optional[str] = None):
         if n_contexts < 1:
             raise ValueError("n_contexts must be >= 1")
+        # Every context has its own HIP stream; HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable
+        # says otherwise) and reads it ONCE, when the runtime initialises.  `import mellow_amd` sets it to 8 if the host has not --
+        # which has no effect when the host process touched the GPU before the import.  With fewer queues than contexts two
+        # contexts share a queue and serialise (right answers, `pipelined` 543 -> 443 responses/s measured): say so.
+        import os
+        import warnings
+        q = os.environ.get("GPU_MAX_HW_QUEUES")
+        if n_contexts > 1 and (q is None or not q.isdigit() or int(q) < min(8, n_contexts + 1)):
+            warnings.warn(f"EnginePool({n_contexts} contexts): GPU_MAX_HW_QUEUES={q!r}; export GPU_MAX_HW_QUEUES=8 before the process's "
+                          "first GPU call, or the contexts will share hardware queues and partly serialise")
+        if n_contexts > 1 and torch.cuda.is_initialized() and os.environ.get("MELLOW_HWQ_SET_BY_IMPORT") == "1":
+            warnings.warn("EnginePool: the GPU was initialised before `import mellow_amd` set GPU_MAX_HW_QUEUES=8, so HIP may still map "
+                          "streams onto 4 hardware queues; export the variable in the environment of the process instead")
         first = Engine(lm=lm, device=device, max_positions=max_positions, precision=precision)
         first.load_state_dict(state_dict)
         self.engines: List[Engine] = [first] + [first.fork() for _ in range(n_contexts - 1)]      # one weight arena, N contexts
