@@ -458,6 +458,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
     const int pm = L / p.gn, pn = L % p.gn;
     const int KT = g.K >> 4;
     // waves 0,1 carry the A stage (chunks wave*6 .. +5 of 12), waves 2,3 the W stage
+    // norm-free chaining (kernels.h, rs_*): the row scales of this workgroup's 128 rows are formed here, while the first
+    // LDS-DMA stages are in flight, so that the epilogue finds them in LDS instead of starting with nine dependent loads per row
+    __shared__ float rs_rows[BM];
+    if (g.rs_ssq && tid < BM) {
+        int64_t m = (int64_t)pm * BM + tid;
+        m = m < g.M ? m : g.M - 1;
+        const float* sp = g.rs_ssq + m * g.rs_parts;
+        float ss = 0.f;
+        for (int p = 0; p < g.rs_parts; ++p) ss += sp[p];             // fixed order
+        rs_rows[tid] = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
+    }
     const bool isA = wave < 2;
     const int c0 = (wave & 1) * 6;
     const char* base = isA ? reinterpret_cast<const char*>(g.A8) + ((int64_t)pm * KT * 12 + c0) * 1024
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
 #undef X3Q_SCHED
 #undef X3Q_ITER
 #undef X3Q_WAIT
-    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
+    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN, g.rs_ssq ? rs_rows : nullptr);   // (written before the main loop's barriers)
 }
 
 #undef MELLOW_BF

@@ -10,7 +10,8 @@ namespace mellow {
 
 template <int WN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int pm, int pn, int wm, int wn,
-                                              int lane, int BM, int BN) {
+                                              int lane, int BM, int BN, const float* rs_rows = nullptr) {
+    // rs_rows (optional): the row scales of this workgroup's BM rows, computed by the kernel BEFORE its main loop (LDS)
     // ---- epilogue: lane owns row m_local = lane&31 of each m-tile, columns 8g + 4h + (0..3) ----------
     const int h = lane >> 5;
 #pragma unroll
@@ -20,10 +21,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         if (g.rs_ssq) {
             // RMSNorm folded into this GEMM: the norm weight sits in the weight columns, the row statistic comes from the
             // producer's per-64-column partial sums (fixed order), and (x W'^T) r = (x r) W'^T up to fp32 rounding
-            const float* sp = g.rs_ssq + (int64_t)m * g.rs_parts;
-            float ss = 0.f;
-            for (int p = 0; p < g.rs_parts; ++p) ss += sp[p];
-            const float r = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
+            float r;
+            if (rs_rows) {
+                r = rs_rows[wm * 64 + mi * 32 + (lane & 31)];
+            } else {
+                const float* sp = g.rs_ssq + (int64_t)m * g.rs_parts;
+                float ss = 0.f;
+                for (int p = 0; p < g.rs_parts; ++p) ss += sp[p];
+                r = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
+            }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
