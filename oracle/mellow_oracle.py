@@ -18,8 +18,8 @@ PINNING:
     does not have: torchlibrosa 0.1.0 (STFT/log-mel op sequence restated from its published
     algorithm; its constants are checkpoint tensors so only the op order is restated),
     transformers 4.46.3 `LlamaForCausalLM` (checked against the installed transformers 5.15 Llama
-    instead, same math), torchaudio 2.0.1 load/resample (host ingest, not in this file), and the
-    SmolLM2 tokenizer files.  The reference itself ships no tests or golden vectors.
+    instead, same math), torchaudio 2.0.1's binary (its published resampling algorithm has its own
+    independent fp64 oracle: oracle/resample_oracle.py), and the SmolLM2 tokenizer files.  The reference itself ships no tests or golden vectors.
 """
 from __future__ import annotations
 

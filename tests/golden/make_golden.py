@@ -224,6 +224,30 @@ def b32_case(args, model, t0):
 
 
 B64_STEPS = 16
+B32LONG_STEPS = 300
+B32LONG_KEEP = (63, 150, 299)
+
+
+def b32long_case(args, model, t0):
+    """BASELINE configs[2]'s per-rank workload through the reference itself: the 32 benchmarked examples for max_len = 300 (the
+    reference re-forwards the whole 389..688-token sequence per step: ~1.5 h on the build container's 8 cores).  Stored: all
+    32 x 300 greedy tokens, every step's maximum logit and top-2 gap, sub-vocabulary logits of steps 63 / 150 / 299."""
+    a1, a2, ids = synth.make_batch(32)
+    with torch.no_grad():
+        prefix, _, _ = model.generate_prefix_inference({"audio1": torch.from_numpy(a1), "audio2": torch.from_numpy(a2),
+                                                        "input": {"input_ids": torch.from_numpy(ids)}})
+        _, toks, logits_log = ref_generate_tokens(model, prefix, B32LONG_STEPS, stop_id=-1)
+    toks = np.asarray(toks, dtype=np.int64)
+    assert toks.shape == (32, B32LONG_STEPS)
+    gaps = np.stack([(lambda t2: (t2[..., 0] - t2[..., 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in logits_log])
+    print(f"b32long: {B32LONG_STEPS} reference steps of 32 rows ({time.time() - t0:.1f}s); min top-2 gap {gaps.min():.4f} at step "
+          f"{int(np.argmin(gaps.min(1)))}")
+    b32 = np.load(os.path.join(HERE, "b32.npz"))["tokens"]
+    assert np.array_equal(toks[:, : b32.shape[1]], b32)
+    np.savez_compressed(os.path.join(args.out, "b32long.npz"), steps=B32LONG_STEPS, tokens=toks, top2_gap=gaps.astype(np.float32),
+                        keep_steps=np.asarray(B32LONG_KEEP), sub_vocab=SUB_VOCAB,
+                        logits_sub=torch.stack([logits_log[i][:, SUB_VOCAB] for i in B32LONG_KEEP]).numpy(),
+                        logits_max=torch.stack([l.max(-1).values for l in logits_log]).numpy())
 
 
 def cfg3_case(args, model, t0):
@@ -398,7 +422,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--skip-long", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64,cfg3,example "
+    ap.add_argument("--only", default="", help="comma list of cases to (re)generate: enc10,gen,long30,late,ragged,eos,forward,b32,b64,cfg3,b32long,example "
                                                "(default: all); enc10 is always computed (the others start from its prefix)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -499,6 +523,8 @@ def main():
         b64_tail_case(args, model, t0)
     if "cfg3" in only or (not only and not args.skip_long):
         cfg3_case(args, model, t0)
+    if "b32long" in only:               # only on request: 1.5 hours
+        b32long_case(args, model, t0)
     if want("ragged") or want("eos"):
         ragged_eos_cases(args, model, sd, lmp, t0, want)
     if want("example"):
