@@ -27,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared between these two pragmas are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* 2: out_tokens may hold -1 (never-computed steps), first_token_ms is host wall-clock time, a decode step needs a prefill of
  *    its own after mellow_generate / mellow_lm_forward_logits, the optional "mellow.rope_cos/sin" tensors, new symbols */
@@ -238,6 +242,9 @@ int  mellow_host_pack_weight(const float* w, int N, int K, int npad, float* out,
  * cos_out / sin_out host f32 [max_pos][head_dim/2]. */
 int  mellow_host_rope_tables(float theta, int head_dim, int max_pos, float* cos_out, float* sin_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

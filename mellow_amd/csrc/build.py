@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libmellow_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_fp8.hip", "gemm_bf16x3.hip", "decode.hip", "prefill_attn.hip", "encoder.hip", "stft_fft.hip", "engine.cpp", "engine_weights.cpp", "engine_encoder.cpp", "engine_lm.cpp", "engine_dev.cpp"]
 HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "engine_internal.h", os.path.join("..", "..", "include", "mellow_hip.h")]
 ARCH = "gfx950"
-FLAGS = (["-DMELLOW_KDEBUG"] if os.environ.get("MELLOW_KDEBUG") else []) + os.environ.get("MELLOW_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+FLAGS = (["-DMELLOW_KDEBUG"] if os.environ.get("MELLOW_KDEBUG") else []) + os.environ.get("MELLOW_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-x", "hip"]
 
 

@@ -5,7 +5,7 @@ extern "C" {
 
 // developer instrumentation (not part of the public header): time `iters` launches of one plain GEMM shape on
 // synthetic device buffers (garbage-in; EPI_LINEAR, no bias) -> average milliseconds per launch
-int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, float* ms_out) {
+__attribute__((visibility("default"))) int mellow_dev_gemm_time(mellow_engine_t* e, int M, int N, int K, int iters, float* ms_out) {
     if (!e || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || iters <= 0 || !ms_out) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));
     float *A = nullptr, *W = nullptr, *Cc = nullptr;
@@ -144,7 +144,7 @@ int mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, cons
 }
 
 // developer instrumentation (not part of the public header): one CSV line per profiled launch
-int mellow_dev_prof_dump(mellow_engine_t* e, const char* path) {
+__attribute__((visibility("default"))) int mellow_dev_prof_dump(mellow_engine_t* e, const char* path) {
     if (!e || !path) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -161,7 +161,7 @@ int mellow_dev_prof_dump(mellow_engine_t* e, const char* path) {
 }
 
 // developer instrumentation (not part of the public header): s_memtime stamps of workgroup 0 of the decode kernels
-int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
+__attribute__((visibility("default"))) int mellow_dev_kdebug(mellow_engine_t* e, int on, uint64_t* host_out64) {
     if (!e) return fail("null engine");
     static uint64_t* buf = nullptr;
     HIPCHK(hipSetDevice(e->device));

@@ -12,7 +12,7 @@ for f in gemm_f32.hip gemm_fp8.hip gemm_bf16x3.hip decode.hip prefill_attn.hip e
   extra=""
   case $f in gemm_bf16x3.hip|gemm_fp8.hip|prefill_attn.hip|encoder.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";;
             decode.hip) extra="-mllvm -amdgpu-kernarg-preload-count=14";; esac     # the per-file flags of build.py
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -x hip $flags $extra -c mellow_amd/csrc/$f -o $tmp/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -x hip $flags $extra -c mellow_amd/csrc/$f -o $tmp/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out $tmp/*.o

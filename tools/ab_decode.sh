@@ -9,7 +9,7 @@ name=$1; flags=$2
 mkdir -p mellow_amd/lib/ab
 out=mellow_amd/lib/ab/libmellow_hip_$name.so
 tmp=$(mktemp -d)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -x hip $flags -mllvm -amdgpu-kernarg-preload-count=14 \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -x hip $flags -mllvm -amdgpu-kernarg-preload-count=14 \
     -c mellow_amd/csrc/decode.hip -o $tmp/decode.hip.o
 objs=$(ls mellow_amd/csrc/build/*.o | grep -v decode.hip.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out $objs $tmp/decode.hip.o
