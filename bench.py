@@ -502,6 +502,9 @@ def main():
                          "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
                          "flops_per_step": flops_alg,
                          "achieved_dense_dft": round(tf_dense, 2),
+                         "gemm_plus_norm_ms": round(g["ms"] + rep["norm"]["ms"], 3),
+                         "gemm_plus_norm_note": "family time + the normalisation launches beside it: since round 4 the LM prefill's RMSNorms live in "
+                                                "the GEMM epilogues (round 3: 19.6 + 2.37 ms), so this sum is the like-for-like figure across rounds",
                          "note": "achieved = algorithmic flops (STFT priced as an FFT, SURVEY 8d) / family time measured live with "
                                  "HIP events on the engine's stream; achieved_dense_dft counts the DFT GEMM's own flops"},
             "roofline": None,
