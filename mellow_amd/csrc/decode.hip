@@ -32,8 +32,18 @@ __device__ uint64_t* g_kdbg = nullptr;
 __device__ __forceinline__ void kstamp(int slot, int idx, bool who) {
     if (g_kdbg && who) g_kdbg[slot * 8 + idx] = __builtin_readcyclecounter();
 }
+// span of a whole launch: earliest start / latest end over ALL its workgroups on the constant 100 MHz clock (s_memrealtime,
+// one counter for the device), at g_kdbg[64 + 2 * seq (+1)]; seq = DecArgs::dbg_seq, set per launch by the host
+__device__ __forceinline__ void kspan(int seq, int end) {
+    if (g_kdbg && seq >= 0 && seq < 480 && threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        if (end) atomicMax(reinterpret_cast<unsigned long long*>(g_kdbg) + 64 + 2 * seq + 1, t);
+        else atomicMin(reinterpret_cast<unsigned long long*>(g_kdbg) + 64 + 2 * seq, t);
+    }
+}
 #else
 #define kstamp(slot, idx, who) ((void)0)
+#define kspan(seq, end) ((void)0)
 #endif
 void set_kernel_debug_buffer(uint64_t* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &p, sizeof(p)); }
 
@@ -163,6 +173,7 @@ template <int KCD, bool BLK, bool FIRST, int W8>      // W8: 0 fp32 weights, 1 e
 __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __restrict__ Wp, const float* __restrict__ xmidF_p,
                                                               const float* __restrict__ dslabF_p, int K8p, const DecArgs a,
                                                               const float* __restrict__ wscale) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[QW * 16 * 64];
     __shared__ float ssq_s[QW * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __res
     }
     if (n < 960)
         *reinterpret_cast<float4*>(a.pq + ((int64_t)kc * a.rows + rb * 32 + mm) * 960 + n) = make_float4(v[0], v[1], v[2], v[3]);
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
                                                                   const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
                                                                   const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
                                                                   const DecArgs a) {
+    kspan(a.dbg_seq, 0);
     // (the leading scalar arguments repeat fields of `a`: the first 14 dwords of the argument block are preloaded into SGPRs
     //  by the command processor -- build.py, -amdgpu-kernarg-preload-count -- so the K/V and slab addresses do not wait for a
     //  scalar load from the argument buffer at the start of every launch)
@@ -605,6 +618,7 @@ _Pragma("unroll")                                                               
             *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
     }
     kstamp(1, 6, dbg);
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -630,6 +644,7 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
                                                                   const float* __restrict__ att_ml_p, const float* __restrict__ xnewR_p,
                                                                   int RB_p, int rows_p, const DecArgs a,
                                                                   const float* __restrict__ wscale) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[OP_WAVES * 4 * 64];   // [wave][acc reg][lane]
     constexpr int K16 = 36, TPW = (K16 + OP_WAVES - 1) / OP_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -745,6 +760,7 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         ss += dpp_mov<0x4E>(ss);
         if (enq == 0) a.ssq[erow * 40 + nt] = ss;
     }
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -760,6 +776,7 @@ constexpr int LM_WAVES = MELLOW_LM_WAVES;
 template <int OUT, bool BLK, int W8>
 __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
                                                         int N, const DecArgs a, const float* __restrict__ wscale) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[LM_WAVES * 16 * 64];
     constexpr int KPW = 72 / LM_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -851,6 +868,7 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
             a.cand_idx[o] = idx;
         }
     }
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -868,6 +886,7 @@ template <bool BLK, int W8>
 __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const float* __restrict__ Wp16, const float* __restrict__ xF16,
                                                                      const float* __restrict__ ssq_in, const DecArgs a,
                                                                      const float* __restrict__ wscale) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[GU_WAVES * 8 * 64];
     constexpr int K16 = 36, TPW = K16 / GU_WAVES;
     static_assert(TPW * GU_WAVES == K16, "waves must divide the 36 k16-tiles");
@@ -955,6 +974,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup16_kernel(const float
         // hidden unit k = 8*nt + 4*q + r: down k-tile nt, F32-layout lane' = m + 32*q
         st_out(reinterpret_cast<float4*>(a.guF) + ((int64_t)rb * 192 + nt) * 64 + m + 32 * q, make_float4(h[0], h[1], h[2], h[3]));
     }
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -971,6 +991,7 @@ static_assert(DN_WAVES >= 4 && 192 % (8 * DN_WAVES) == 0, "the epilogue needs 25
 template <bool BLK, int W8>
 __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const float* __restrict__ Wp, const float* __restrict__ guF_p, int K8p,
                                                                  const DecArgs a, const float* __restrict__ wscale) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[DN_WAVES * 16 * 64];
     constexpr int KPW = 192 / (DEC_KC_DOWN * DN_WAVES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1035,6 +1056,7 @@ __global__ __launch_bounds__(DN_WAVES * 64) void dec_down_kernel(const float* __
         reinterpret_cast<float4*>(a.dslabF)[(int64_t)kc * a.slabF_stride4 + f32_idx(rb, 72, mm, n)] = make_float4(v[0], v[1], v[2], v[3]);
     }
     kstamp(4, 4, dbg);
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1059,6 +1081,7 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
                                                             const float* __restrict__ guF_p, int K8x, int K8h, const DecArgs a,
                                                             const float* __restrict__ sc_x, const float* __restrict__ sc_h,
                                                             const float* __restrict__ sc_d) {
+    kspan(a.dbg_seq, 0);
     __shared__ __attribute__((aligned(16))) float red[Q2W * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, rb = blockIdx.y;
@@ -1169,6 +1192,7 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
         else st_out(reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n), o);
     }
     kstamp(7, 4, dbg);
+    kspan(a.dbg_seq, 1);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1178,6 +1202,7 @@ __global__ __launch_bounds__(Q2W * 64) void dec_qkv2_kernel(const float* __restr
 template <int KCD, bool BLK>
 __global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __restrict__ norm_w, const float* __restrict__ xmidF_p,
                                                              const float* __restrict__ dslabF_p, int64_t stride4_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
     __shared__ float part[3];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (BLK && b == 0 && tid < 32) a.blk_snap[tid] = a.blk_live[tid];      // for this step's arg-max (kernels.h)
@@ -1202,6 +1227,7 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __rest
         y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
         reinterpret_cast<float4*>(a.xnF)[fi] = y;
     }
+    kspan(a.dbg_seq, 1);
 }
 
 // arg-max over the lm_head's per-tile candidates, fused with the loop bookkeeping of reference wrapper.py:232-249:
@@ -1210,6 +1236,7 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dec_argmax_kernel(const float* __restrict__ cand_val_p, const int32_t* __restrict__ cand_idx_p, int n,
                                                          const DecArgs a, int32_t* __restrict__ tokens,
                                                          const float* __restrict__ embed, int write_x, const LoopArgs lp) {
+    kspan(a.dbg_seq, 0);
     __shared__ float bv[4];
     __shared__ int bi[4];
     __shared__ int tok_s;
@@ -1277,6 +1304,7 @@ __global__ __launch_bounds__(256) void dec_argmax_kernel(const float* __restrict
             reinterpret_cast<float4*>(a.xmidF)[f32_idx(b >> 5, 72, b & 31, tid * 4)] = e;
         }
     }
+    kspan(a.dbg_seq, 1);
 }
 
 // Row migration (reference stop rule, more than one 32-row block).  One workgroup, after the step's arg-max: the rows that

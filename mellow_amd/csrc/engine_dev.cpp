@@ -166,16 +166,32 @@ __attribute__((visibility("default"))) int mellow_dev_kdebug(mellow_engine_t* e,
     static uint64_t* buf = nullptr;
     HIPCHK(hipSetDevice(e->device));
     if (on) {
-        if (!buf) HIPCHK(hipMalloc(&buf, 64 * sizeof(uint64_t)));
-        HIPCHK(hipMemset(buf, 0, 64 * sizeof(uint64_t)));
+        // [0, 64): phase stamps of workgroup 0; [64, 1024): (earliest start, latest end) of every launch of a decode step
+        // (DecArgs::dbg_seq, 100 MHz clock), the starts initialised to the maximum
+        if (!buf) HIPCHK(hipMalloc(&buf, 1024 * sizeof(uint64_t)));
+        std::vector<uint64_t> init(1024, 0);
+        for (int i = 64; i < 1024; i += 2) init[i] = ~0ull;
+        HIPCHK(hipMemcpy(buf, init.data(), 1024 * sizeof(uint64_t), hipMemcpyHostToDevice));
         set_kernel_debug_buffer(buf);
         set_gemm_debug_buffer(buf);
+        e->dbg_seq0 = 0;
     } else {
         HIPCHK(hipStreamSynchronize(e->stream));
+        e->dbg_seq0 = -1;
+        // (host_out64 receives the 64 phase stamps; mellow_dev_kdebug_spans the launch spans)
         if (buf && host_out64) HIPCHK(hipMemcpy(host_out64, buf, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (buf) HIPCHK(hipMemcpy(e->dbg_spans, buf + 64, 960 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         set_kernel_debug_buffer(nullptr);
         set_gemm_debug_buffer(nullptr);
     }
+    return 0;
+}
+
+// the launch spans collected by the last mellow_dev_kdebug(on) .. (off) bracket: out[2 i] / out[2 i + 1] = earliest start / latest
+// end (10 ns ticks) of launch i of the LAST decode step that ran inside the bracket; 480 pairs
+__attribute__((visibility("default"))) int mellow_dev_kdebug_spans(mellow_engine_t* e, uint64_t* out960) {
+    if (!e || !out960) return fail("null argument");
+    memcpy(out960, e->dbg_spans, 960 * sizeof(uint64_t));
     return 0;
 }
 

@@ -193,6 +193,8 @@ struct mellow_engine {
     // the q/k/v and gate/up GEMMs run on norm-folded weights and scale their accumulators by the row statistic (run_prefill).
     // MELLOW_PREFILL_FUSE_NORM=0: the two-launch form (developer A/B), read when the engine is created.
     bool prefill_fuse_norm = true;
+    uint64_t dbg_spans[960] = {};
+    int dbg_seq0 = -1;                           // developer stamps (mellow_dev_kdebug): first launch index of a decode step, -1 = off
     int dec_fuse_max_rb = 1;                     // decode: largest number of 32-row blocks that runs the fused down + q/k/v launch (fp32 weights)
     mellow_engine* parent = nullptr;             // a fork: the context whose weights it shares
     int n_forks = 0, prefill_parts_saved = 2;    // a parent: live forks; its own split setting, restored when the last fork goes

@@ -111,13 +111,14 @@ LoopArgs loop_args(mellow_engine* e) {
 // final norm (+ pending down slabs) + lm_head with fused per-tile arg-max candidates -> dlogits, d_tokens
 int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArgs* rec) {
     const int NT = e->cfg.vocab_size / 32, Bp = e->da.rows;
+    auto dh = [&](int k) { DecArgs x = e->da; x.dbg_seq = e->dbg_seq0 >= 0 ? e->dbg_seq0 + 5 * e->cfg.num_layers + k : -1000; return x; };
     { ProfScope ps(e, PF_NORM, 0, (double)(pending_kcd + 2) * Bp * 576 * 4);
-      launch_dec_final_norm(e->da, e->final_norm, pending_kcd, e->stream); }
+      launch_dec_final_norm(dh(0), e->final_norm, pending_kcd, e->stream); }
     { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * e->cfg.vocab_size, 576.0 * e->cfg.vocab_size * 4);
-      if (e->head8) launch_dec_lm_head(e->da, e->head8, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream, e->head_sc);
-      else launch_dec_lm_head(e->da, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
+      if (e->head8) launch_dec_lm_head(dh(1), e->head8, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream, e->head_sc);
+      else launch_dec_lm_head(dh(1), e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream); }
     { ProfScope ps(e, PF_MISC, 0, 0);
-      launch_dec_argmax(e->da, B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? loop_args(e) : LoopArgs(),
+      launch_dec_argmax(dh(2), B, NT, e->d_tokens, e->embed, (rec && rec->embed_next) ? 1 : 0, rec ? loop_args(e) : LoopArgs(),
                         e->stream);
       if (rec && e->da.row_of_slot) launch_dec_compact(e->da, B, loop_args(e), e->stream); }
     return 0;
@@ -280,6 +281,9 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
         const bool fuse_rb = e->da.RB <= e->dec_fuse_max_rb;
         const bool fused_in = l > l_begin && ((w.qkv2 != nullptr && fuse_rb) || w.q2h8 != nullptr) && !same_w;
         DecArgs a = e->da;
+        const int sq = e->dbg_seq0 >= 0 ? e->dbg_seq0 + 5 * (l - l_begin) : -1000;       // launch index inside the step (kdebug builds)
+        auto da = [&](int k) { DecArgs x = e->da; x.dbg_seq = sq + k; return x; };
+        a.dbg_seq = sq;
         a.first = l == l_begin ? 1 : 0;                     // the first kernel of a step stages the RoPE row ...
         a.inc_pos = (inc_pos && l == l_begin) ? 1 : 0;     // ... and advances the position word
         if (!(skip & 1) && !fused_in)
@@ -288,26 +292,26 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
           else launch_dec_qkv(a, w.qkv_f.p, w.qkv_f.KP / 8, kcd, s); }
         if (!(skip & 2))
         { ProfScope ps(e, PF_DECODE_ATTN, 4.0 * 64 * 9 * (double)B * (e->cur_pos + 1), 2.0 * (double)B * 3 * 64 * 4 * (e->cur_pos + 1));
-          launch_dec_attn(e->da, kc, vc, fused_in, s); }
+          launch_dec_attn(da(1), kc, vc, fused_in, s); }
         if (!(skip & 4))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 576.0, 576.0 * 576.0 * 4);
-          if (w.o8) launch_dec_oproj(e->da, w.o8, s, w.o_sc);
-          else launch_dec_oproj(e->da, w.o16, s); }
+          if (w.o8) launch_dec_oproj(da(2), w.o8, s, w.o_sc);
+          else launch_dec_oproj(da(2), w.o16, s); }
         if (!(skip & 8))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
-          if (w.gu8) launch_dec_gateup(e->da, w.gu8, s, w.gu_sc);
-          else launch_dec_gateup(e->da, w.gu16, s); }
+          if (w.gu8) launch_dec_gateup(da(3), w.gu8, s, w.gu_sc);
+          else launch_dec_gateup(da(3), w.gu16, s); }
         const LMLayerW* nx = (l + 1 < l_end && !same_w) ? &e->layers[l + 1] : nullptr;
         if (nx && ((nx->qkv2 && fuse_rb) || nx->q2h8)) {
             // the down projection of this layer and the q/k/v projection of the next one as one launch (decode.hip, dec_qkv2_kernel)
             if (!(skip & 16))
             { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * (nx->q2h8 ? 1 : 4));
-              if (nx->q2h8) launch_dec_qkv2_w8(e->da, nx->qkv8, nx->qkv_sc, nx->q2h8, nx->q2h_sc, w.dn8, w.dn_sc, s);
-              else launch_dec_qkv2(e->da, nx->qkv2, w.down.p, s); }
+              if (nx->q2h8) launch_dec_qkv2_w8(da(4), nx->qkv8, nx->qkv_sc, nx->q2h8, nx->q2h_sc, w.dn8, w.dn_sc, s);
+              else launch_dec_qkv2(da(4), nx->qkv2, w.down.p, s); }
         } else if (!(skip & 16))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);
-          if (w.dn8) launch_dec_down(e->da, w.dn8, w.down.KP / 8, s, w.dn_sc);
-          else launch_dec_down(e->da, w.down.p, w.down.KP / 8, s); }
+          if (w.dn8) launch_dec_down(da(4), w.dn8, w.down.KP / 8, s, w.dn_sc);
+          else launch_dec_down(da(4), w.down.p, w.down.KP / 8, s); }
     }
     return 0;
 }

@@ -158,6 +158,7 @@ struct DecArgs {
     // whenever that empties a whole 32-row block.
     const int32_t* row_of_slot = nullptr;
     int a8 = 0;                    // fp8 mode: launches that get e4m3 weights also quantise their activations (fp8 matrix pipe)
+    int dbg_seq = -1;              // -DMELLOW_KDEBUG builds: index of this launch in the step (span stamps of tools/kdebug.py), else unused
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]
 };
