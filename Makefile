@@ -14,6 +14,6 @@ bench: lib
 	$(PY) bench.py
 
 microbench:
-	for f in mfma_peak gemm_ablate grid_sync; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/$$f.bin tools/microbench/$$f.hip; done
+	for f in mfma_peak gemm_ablate grid_sync grid_sync2 stage_emul fused_og_emul; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/$$f.bin tools/microbench/$$f.hip; done
 
 .PHONY: lib test-cpu test-gpu bench microbench
