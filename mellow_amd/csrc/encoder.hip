@@ -203,6 +203,101 @@ void launch_merge_layernorm(const float* in, float* out, int n, int R, int C, co
                        (const int32_t*)nullptr, 0, R, C);
 }
 
+// The row-map LayerNorm with its output pre-split in APB order (f32x3 mode: the consumer is an x3q GEMM, common.h).  Same
+// statistics as layernorm_kernel<0> bit for bit (same lane -> column mapping, same reduction order, same expression for y);
+// a workgroup owns 32 consecutive OUTPUT rows: pass 1 gathers them (one row per wave at a time, coalesced), keeps them in LDS
+// and forms mean / rstd; pass 2 re-reads them from LDS in the (row % 32, k-half) order of an APB slot run, so that every store
+// instruction of a wave writes 1 KiB contiguous (the scheme of rmsnorm_apb_kernel below).  NQ = float4 per lane (C <= 256 NQ).
+template <int NQ>
+__global__ __launch_bounds__(256) void layernorm_apb_kernel(const float* __restrict__ in, i32x4* __restrict__ out, int64_t M, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const int32_t* __restrict__ row_map, int ntok) {
+    extern __shared__ __attribute__((aligned(16))) float ln_rows_s[];
+    __shared__ float mu_s[32], rs_s[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2, KT = C >> 4, RS = C + 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    float4 x[8][NQ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t m = m0 + wave * 8 + i;
+        m = m < M ? m : M - 1;
+        int64_t src = m;
+        if (row_map) src = (m / ntok) * ntok + row_map[m % ntok];
+        const float4* sp = reinterpret_cast<const float4*>(in + src * C);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = lane + 64 * q;
+            x[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < nv) x[i][q] = sp[v];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4* dst = reinterpret_cast<float4*>(ln_rows_s + (wave * 8 + i) * RS);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = lane + 64 * q;
+            if (v < nv) {
+                dst[v] = x[i][q];
+                sum += (x[i][q].x + x[i][q].y) + (x[i][q].z + x[i][q].w);
+            }
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = lane + 64 * q;
+            if (v < nv) {
+                const float a = x[i][q].x - mean, bb = x[i][q].y - mean, c = x[i][q].z - mean, d = x[i][q].w - mean;
+                sq += (a * a + bb * bb) + (c * c + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + 1e-5f);
+        if (lane == 0) { mu_s[wave * 8 + i] = mean; rs_s[wave * 8 + i] = rstd; }
+    }
+    __syncthreads();
+    const int ml = lane & 31;
+    const int64_t m = m0 + ml;
+    if (m >= M) return;
+    const float mean = mu_s[ml], rstd = rs_s[ml];
+    const int kh = lane >> 5;
+    for (int kt = wave; kt < KT; kt += 4) {
+        const int col = kt * 16 + kh * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(ln_rows_s + ml * RS + col), x1 = *reinterpret_cast<const float4*>(ln_rows_s + ml * RS + col + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(w + col), w1 = *reinterpret_cast<const float4*>(w + col + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + col), b1 = *reinterpret_cast<const float4*>(b + col + 4);
+        float y[8];
+        y[0] = (x0.x - mean) * rstd * w0.x + b0.x;
+        y[1] = (x0.y - mean) * rstd * w0.y + b0.y;
+        y[2] = (x0.z - mean) * rstd * w0.z + b0.z;
+        y[3] = (x0.w - mean) * rstd * w0.w + b0.w;
+        y[4] = (x1.x - mean) * rstd * w1.x + b1.x;
+        y[5] = (x1.y - mean) * rstd * w1.y + b1.y;
+        y[6] = (x1.z - mean) * rstd * w1.z + b1.z;
+        y[7] = (x1.w - mean) * rstd * w1.w + b1.w;
+        apb_store8(out, m, kt * 2 + kh, KT, y);
+    }
+}
+// C % 16 == 0, C <= 768; out_apb holds roundup(M, 128) rows (rows >= M are left as they are: their products are never stored)
+void launch_layernorm_apb(const float* in, void* out_apb, int M, int C, const float* w, const float* b, const int32_t* row_map,
+                          int ntok, hipStream_t s) {
+    const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 98.8 KB at C = 768
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid((M + 31) / 32), block(256);
+    i32x4* o = reinterpret_cast<i32x4*>(out_apb);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_apb_kernel<1>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
+    else if (C <= 512) hipLaunchKernelGGL((layernorm_apb_kernel<2>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
+    else hipLaunchKernelGGL((layernorm_apb_kernel<3>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
+}
+
 // LlamaRMSNorm (fp32): w * (x * rsqrt(mean(x^2) + eps))
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t M,
                                                       int C, const float* __restrict__ w, float eps) {
@@ -384,10 +479,12 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
 //     floats of its q / k row (3 float4 loads each, straight from global memory: no LDS for Q or K);
 //   * V^T operand: V[key][d = lane % 32] from a row-major LDS copy of the wave's 64 x 24 V tile (lanes 24..31 multiply zeros:
 //     the 32-row output tile is 25 % padding);  48 + 64 = 112 MFMAs per tile instead of 3072 FMAs + 768 LDS broadcasts per lane.
+//   * out_apb (f32x3 mode, the proj GEMM runs on the x3q kernel): the output goes out pre-split in APB order instead of fp32 --
+//     a lane's quads are the epilogue quads of the GEMMs (common.h: apb_store_quads), head_dim 24 = three 8-column groups.
 __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                     int C, int nH, const float* __restrict__ bias_exp,
                                                                     const float* __restrict__ mask, int nW,
-                                                                    int64_t n_tiles) {
+                                                                    int64_t n_tiles, i32x4* __restrict__ out_apb) {
     __shared__ __attribute__((aligned(16))) float Vs[4][64 * 24];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;   // tile = window * nH + head
@@ -484,7 +581,24 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float*
             O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[kt][0][r], O[0], 0, 0, 0);
             O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[kt][1][r], O[1], 0, 0, 0);
         }
-    if (active) {
+    if (active && out_apb) {
+        const int KT = C >> 4;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int64_t m = win * 64 + qt * 32 + ml;
+            float X[4], Y[4], Z[4], w[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { X[j] = O[qt][j] * inv[qt]; Y[j] = O[qt][4 + j] * inv[qt]; Z[j] = O[qt][8 + j] * inv[qt]; }
+            apb_store_quads(out_apb, m, hd * 3, KT, X, Y, h);           // d = 0..7 (lower half-wave), 8..15 (upper)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(Z[j]), __float_as_uint(Z[j]), false, false);
+                w[j] = __uint_as_float(r[0]);
+                w[4 + j] = __uint_as_float(r[1]);
+            }
+            if (h == 0) apb_store8(out_apb, m, hd * 3 + 2, KT, w);      // d = 16..23
+        }
+    } else if (active) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float* dst = out + (win * 64 + qt * 32 + ml) * C + hd * 24;
@@ -498,15 +612,15 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float*
     }
 }
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
-                             const float* mask, int nW, hipStream_t s) {
+                             const float* mask, int nW, hipStream_t s, void* out_apb) {
     const int64_t n_tiles = (int64_t)(M / 64) * nH;
     static const bool valu = getenv("MELLOW_WINATTN_VALU") != nullptr;     // developer A/B: the VALU kernel above
-    if (valu)
+    if (valu && !out_apb)
         hipLaunchKernelGGL(window_attention_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
                            bias_exp, mask, nW, n_tiles);
     else
         hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
-                           bias_exp, mask, nW, n_tiles);
+                           bias_exp, mask, nW, n_tiles, reinterpret_cast<i32x4*>(out_apb));
 }
 
 // ---- A10 tail: latent mean + im2col for the token-semantic conv (htsat.py:742-775) ---------------------------

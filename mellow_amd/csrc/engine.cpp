@@ -242,6 +242,8 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     if (const char* pp = getenv("MELLOW_PREFILL_SPLIT")) e->prefill_parts = atoi(pp);
     if (const char* fn = getenv("MELLOW_PREFILL_FUSE_NORM")) e->prefill_fuse_norm = fn[0] != '0';
     if (const char* fr = getenv("MELLOW_DECODE_FUSE_MAX_RB")) e->dec_fuse_max_rb = atoi(fr);
+    if (const char* sk = getenv("MELLOW_SPLITK")) e->sk_max = atoi(sk);
+    if (const char* ea = getenv("MELLOW_ENC_APB")) e->enc_apb_stages = (int)strtol(ea, nullptr, 0);
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));      // (streams: on first use)
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
@@ -263,7 +265,7 @@ void mellow_engine_destroy(mellow_engine_t* e) {
     for (void* p : e->allocs) hipFree(p);      // a fork's list holds only what it allocated itself (resample banks): the weights are its parent's
     mellow_engine::Buf* bufs[] = {&e->wavcat, &e->wpad, &e->power, &e->logmel, &e->X0, &e->X1, &e->T, &e->QKV, &e->H, &e->ats,
                                   &e->fpx, &e->fpxavg, &e->latv, &e->emb33, &e->e1, &e->gbuf, &e->sbuf, &e->proj33,
-                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->lm_xn3, &e->lm_o3, &e->lm_h3, &e->lm_ssq, &e->kcache, &e->vcache, &e->dec,
+                                  &e->lm_x, &e->lm_xn, &e->lm_q, &e->lm_o, &e->lm_h, &e->lm_xn3, &e->lm_o3, &e->lm_h3, &e->lm_ssq, &e->enc_a3, &e->enc_h3, &e->sk_ws, &e->kcache, &e->vcache, &e->dec,
                                   &e->dlogits, &e->cand, &e->out_tok};
     for (auto* b : bufs)
         if (b->p) hipFree(b->p);
@@ -412,7 +414,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     HIPCHK(hipStreamSynchronize(parent->stream));
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
-    c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb;
+    c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb; c->enc_apb_stages = parent->enc_apb_stages; c->sk_max = parent->sk_max;
     c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;

@@ -2,6 +2,13 @@
 #include "engine_internal.h"
 
 // ---- GEMM wrappers -------------------------------------------------------------------------------------------------------
+// split-K workspace of the f32x3 kernels (kernels.h: sk_*), handed to launches of the encoder chain only
+static void with_splitk(mellow_engine* e, GemmArgs& g) {
+    if (!e->sk_enable || e->sk_max < 2 || !e->sk_ws.p) return;
+    g.sk_ws = e->sk_ws.p;
+    g.sk_tiles = 256;
+    g.sk_max = e->sk_max;
+}
 int run_gemm(mellow_engine* e, const GemmArgs& a) {
     // f32x3: every dense GEMM of encoder + prefill, the STFT (EPI_POWER, K = 1024, framed A operand) and the mel projection
     // included (-0.6 ms per pass).  Through the split kernel the power spectrum differs from the ORACLE's fp32 conv1d by 2.5e-6
@@ -17,6 +24,7 @@ int run_gemm(mellow_engine* e, const GemmArgs& a) {
             // pre-split kernel (launch_split_rows + launch_gemm_bf16x3) remains reachable through mellow_debug_gemm_f32
             GemmArgs g = a;
             g.W8 = reinterpret_cast<const uint8_t*>(it->second);
+            with_splitk(e, g);
             ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
             ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 200;
             launch_gemm_bf16x3_fused(g, e->stream);
@@ -53,6 +61,7 @@ int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_
     GemmArgs g = a;
     g.A8 = reinterpret_cast<const uint8_t*>(a3);
     g.W8 = reinterpret_cast<const uint8_t*>(it->second);
+    if (!st || st == e->stream) with_splitk(e, g);
     ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
     ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 300;
     launch_gemm_bf16x3_apb(g, st ? st : e->stream);
@@ -71,6 +80,14 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
     if (n <= 0) return fail("n_clips must be positive");
     if (n_samples % 4 || n_samples < kNfft) return fail("n_samples must be a multiple of 4 and >= 1024");
     hipStream_t s = e->stream;
+    struct SkScope {            // the encoder chain is one stream: its under-filled GEMM launches may use the split-K workspace
+        mellow_engine* e;
+        ~SkScope() { e->sk_enable = false; }
+    } sk_scope{e};
+    if (e->f32x3_terms && e->sk_max >= 2) {
+        CHK(ensure(e, e->sk_ws, (size_t)512 * 16384));
+        e->sk_enable = e->sk_ws.p != nullptr;
+    }
     const int frames = (int)(n_samples / kHop) + 1;
     const int64_t plen = n_samples + kNfft;
     const int M = n * frames;
@@ -132,27 +149,56 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
             const SwinBlockW& w = e->blocks[st][b];
             const bool shifted = (b % 2 == 1) && R > kWin;
             const int32_t* map = R > kWin ? e->win_map[st][shifted ? 1 : 0] : nullptr;
-            { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n1w, w.n1b, map, N, s); }
-            CHK(run_gemm(e, lin(t, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b)));
+            // f32x3 mode, stages in enc_apb_stages: the LayerNorms and the GELU epilogue of fc1 write their output pre-split in APB
+            // order and qkv / fc1 / fc2 run on the LDS-DMA kernel (gemm_x3q_kernel); H never exists as fp32
+            const bool apb = e->f32x3_terms && ((e->enc_apb_stages >> st) & 1) && e->bf_w.count(w.qkv.p) && e->bf_w.count(w.fc1.p) &&
+                             e->bf_w.count(w.fc2.p);
+            const size_t M1p = (size_t)rup(M1, 128);
+            if (apb) {
+                CHK(ensure(e, e->enc_a3, (M1p * C * 6 + 3) / 4));
+                CHK(ensure(e, e->enc_h3, (M1p * 4 * C * 6 + 3) / 4));
+                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n1w, w.n1b, map, N, s); }
+                CHK(run_gemm_apb(e, lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b), e->enc_a3.p, s));
+            } else {
+                { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n1w, w.n1b, map, N, s); }
+                CHK(run_gemm(e, lin(t, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b)));
+            }
+            // bits 4..7 of enc_apb_stages: the window attention hands its output over pre-split too (proj on the x3q kernel)
+            const bool apb_proj = apb && ((e->enc_apb_stages >> (4 + st)) & 1) && e->bf_w.count(w.proj.p);
             {
                 ProfScope ps(e, PF_WINDOW_ATTN, 4.0 * 64 * 64 * 24 * (double)(M1 / 64) * nH, 4.0 * M1 * C * 4);
-                launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s);
+                launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s, apb_proj ? e->enc_a3.p : nullptr);
             }
             {
                 GemmArgs g = lin(t, C, M1, w.proj, x, C, w.proj_b);
                 g.resid = x; g.ldr = C; g.crow_map = map; g.rows_in = N; g.rows_out = N;
-                CHK(run_gemm(e, g));
+                if (apb_proj) CHK(run_gemm_apb(e, g, e->enc_a3.p, s));
+                else CHK(run_gemm(e, g));
             }
-            { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n2w, w.n2b, nullptr, N, s); }
-            {
-                GemmArgs g = lin(t, C, M1, w.fc1, e->H.p, 4 * C, w.fc1_b);
-                g.act = ACT_GELU;
-                CHK(run_gemm(e, g));
-            }
-            {
-                GemmArgs g = lin(e->H.p, 4 * C, M1, w.fc2, x, C, w.fc2_b);
-                g.resid = x; g.ldr = C;
-                CHK(run_gemm(e, g));
+            if (apb) {
+                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n2w, w.n2b, nullptr, N, s); }
+                {
+                    GemmArgs g = lin(nullptr, C, M1, w.fc1, nullptr, 4 * C, w.fc1_b);
+                    g.act = ACT_GELU; g.C3 = e->enc_h3.p;
+                    CHK(run_gemm_apb(e, g, e->enc_a3.p, s));
+                }
+                {
+                    GemmArgs g = lin(nullptr, 4 * C, M1, w.fc2, x, C, w.fc2_b);
+                    g.resid = x; g.ldr = C;
+                    CHK(run_gemm_apb(e, g, e->enc_h3.p, s));
+                }
+            } else {
+                { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n2w, w.n2b, nullptr, N, s); }
+                {
+                    GemmArgs g = lin(t, C, M1, w.fc1, e->H.p, 4 * C, w.fc1_b);
+                    g.act = ACT_GELU;
+                    CHK(run_gemm(e, g));
+                }
+                {
+                    GemmArgs g = lin(e->H.p, 4 * C, M1, w.fc2, x, C, w.fc2_b);
+                    g.resid = x; g.ldr = C;
+                    CHK(run_gemm(e, g));
+                }
             }
         }
         if (st < 3) {

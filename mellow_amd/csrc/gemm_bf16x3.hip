@@ -72,7 +72,64 @@ void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s
 struct GemmBDev {
     GemmArgs a;
     int gm, gn;
+    int ks;                 // split-K: workgroups per output tile (1 = none); tile = L % (gm gn), split = L / (gm gn)
 };
+
+// Split-K for launches that would leave most of the chip idle (<= 256 output tiles: the tail GEMMs of the encoder).  Two
+// launches: every (tile, split) workgroup of the GEMM kernel writes its 128 x 128 fp32 partial tile to the workspace
+// (thread-major 16-byte pieces, coalesced) and leaves; splitk_finish_kernel (one workgroup per tile, the same thread -> element
+// mapping) sums the partials in split order -- a fixed summation order -- and runs the epilogue.  The kernel boundary is the
+// hand-over: the in-kernel forms (the last split to arrive at a counter finishes the tile) were either slow (__threadfence() on
+// both sides: 80-100 us per launch) or wrong (write-through stores + L2-bypassing loads), tools/experiments/r04_encoder_notes.md.
+__device__ __forceinline__ void splitk_store(const GemmBDev& p, const f32x16 (&acc)[2][2], int tile, int split, int tid) {
+    f32x4* ws = reinterpret_cast<f32x4*>(p.a.sk_ws) + ((int64_t)(tile * p.ks + split) * 16) * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ws[((i * 2 + j) * 4 + r) * 256] = f32x4{acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmBDev p) {
+    constexpr int BM = 128, BN = 128, WN = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int pm = tile / p.gn, pn = tile % p.gn;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const f32x4* rs = reinterpret_cast<const f32x4*>(p.a.sk_ws) + ((int64_t)tile * p.ks * 16) * 256 + tid;
+    for (int sp = 0; sp < p.ks; ++sp, rs += 16 * 256) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 v = __builtin_nontemporal_load(rs + ((i * 2 + j) * 4 + r) * 256);
+                    acc[i][j][4 * r] += v.x; acc[i][j][4 * r + 1] += v.y; acc[i][j][4 * r + 2] += v.z; acc[i][j][4 * r + 3] += v.w;
+                }
+    }
+    gemm_epilogue<WN, EPI>(p.a, acc, pm, pn, wave >> 1, wave & 1, lane, BM, BN);
+}
+// host side: splits for a launch of `tiles` output tiles and KT k16 steps: at most 512 workgroups, at least 32 steps per split,
+// and launches that already cover half of the chip are split only when they are long (measured at B = 32, round 4: the
+// token-semantic conv 80 tiles x 288 steps 194 -> 89 us, stage-3 fc2 192 x 192 142 -> 113; stage-3 proj 192 x 48 and the
+// patch-merging reduction 192 x 96: +-0 / +5 us, so those stay whole)
+static int splitk_for(const GemmArgs& a, int tiles, int KT) {
+    if (!a.sk_ws || tiles > 256 || tiles > a.sk_tiles) return 1;
+    if (tiles > 128 && KT < 128) return 1;
+    int s = 512 / tiles;
+    if (s > KT / 32) s = KT / 32;
+    if (s > a.sk_max) s = a.sk_max;
+    return s < 2 ? 1 : s;
+}
 
 #define MELLOW_BF(W, A, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, A), ACC, 0, 0, 0);
 
@@ -295,9 +352,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     const GemmArgs& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
-    const int pm = L / p.gn, pn = L % p.gn;
-    const int KT = g.K >> 4;
+    const int tiles = p.gm * p.gn;
+    const int L = xcd_remap((int)blockIdx.x, tiles * p.ks);
+    const int tile = L % tiles, split = L / tiles;
+    const int pm = tile / p.gn, pn = tile % p.gn;
+    const int KTf = g.K >> 4;
+    const int kt0 = split * KTf / p.ks;
+    const int KT = (split + 1) * KTf / p.ks - kt0;                          // this workgroup's k16 steps (all of them without split-K)
     const i32x4* PB = reinterpret_cast<const i32x4*>(g.W8);
 
     // A staging: thread t owns the 8 consecutive k of (row t/2, k-half t%2) of a k16 tile = exactly one lane's share of an MFMA
@@ -307,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     am = am < g.M ? am : g.M - 1;
     // A_FRAMES (the STFT): row m = frame (m % fpc) of clip (m / fpc), a 1024-sample window starting at hop * frame
     const int64_t a_off = g.a_mode == A_FRAMES ? (int64_t)(am / g.fpc) * g.clip_stride + (int64_t)(am % g.fpc) * g.hop : (int64_t)am * g.lda;
-    const float* a_ptr = g.A + a_off + akh * 8;
+    const float* a_ptr = g.A + a_off + akh * 8 + kt0 * 16;
     const int a_lds = (arow >> 5) * 64 + (arow & 31) + 32 * akh;            // + piece * 256
     const i32x4* w_ptr[3];
     int w_lds[3];
@@ -315,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
     for (int q = 0; q < 3; ++q) {
         const int c = q * 256 + tid;
         const int ntl = c / 192, r2 = c % 192;           // W: [n-tile][piece][lane] per k16
-        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * KT) * 192 + r2;
+        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * KTf + kt0) * 192 + r2;
         w_lds[q] = ((r2 >> 6) * 4 + ntl) * 64 + (r2 & 63);
     }
     f32x16 acc[2][2];
@@ -426,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(const GemmBDev p) {
 #undef X3_SCHED
 #undef X3_ITER
 #undef X3_PRIO
+    if (p.ks > 1) return splitk_store(p, acc, tile, split, tid);
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
 }
 
@@ -454,9 +516,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
-    const int pm = L / p.gn, pn = L % p.gn;
-    const int KT = g.K >> 4;
+    const int tiles = p.gm * p.gn;
+    const int L = xcd_remap((int)blockIdx.x, tiles * p.ks);
+    const int tile = L % tiles, split = L / tiles;
+    const int pm = tile / p.gn, pn = tile % p.gn;
+    const int KTf = g.K >> 4;
+    const int kt0 = split * KTf / p.ks;
+    const int KT = (split + 1) * KTf / p.ks - kt0;                          // this workgroup's k16 steps (split-K, see splitk_store)
     // waves 0,1 carry the A stage (chunks wave*6 .. +5 of 12), waves 2,3 the W stage
     // norm-free chaining (kernels.h, rs_*): the row scales of this workgroup's 128 rows are formed here, while the first
     // LDS-DMA stages are in flight, so that the epilogue finds them in LDS instead of starting with nine dependent loads per row
@@ -471,14 +537,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
     }
     const bool isA = wave < 2;
     const int c0 = (wave & 1) * 6;
-    const char* base = isA ? reinterpret_cast<const char*>(g.A8) + ((int64_t)pm * KT * 12 + c0) * 1024
-                           : reinterpret_cast<const char*>(g.W8) + (int64_t)pn * 4 * KT * 3072;
+    const char* base = isA ? reinterpret_cast<const char*>(g.A8) + (((int64_t)pm * KTf + kt0) * 12 + c0) * 1024
+                           : reinterpret_cast<const char*>(g.W8) + ((int64_t)pn * 4 * KTf + kt0) * 3072;
     const uint32_t kstep = isA ? 12288u : 3072u;
     uint32_t voff[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int c = c0 + j;                                               // W chunk c = piece * 4 + n-tile
-        voff[j] = isA ? (uint32_t)(j * 1024 + lane * 16) : (uint32_t)(((c & 3) * KT * 192 + (c >> 2) * 64 + lane) * 16);
+        voff[j] = isA ? (uint32_t)(j * 1024 + lane * 16) : (uint32_t)(((c & 3) * KTf * 192 + (c >> 2) * 64 + lane) * 16);
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_bf + (isA ? 0u : (uint32_t)(NST * STAGE * 16)) + (uint32_t)c0 * 1024u;
 #define X3Q_ISSUE(T, ST)                                                                         \
@@ -597,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
 #undef X3Q_SCHED
 #undef X3Q_ITER
 #undef X3Q_WAIT
+    if (p.ks > 1) return splitk_store(p, acc, tile, split, tid);
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN, g.rs_ssq ? rs_rows : nullptr);   // (written before the main loop's barriers)
 }
 
@@ -636,13 +703,15 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
     d.a = a;
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
+    d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
     const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                              // 72 KiB
     static bool attr_q = false;
     if (!attr_q) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_q = true;
     }
-    hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
+    if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
 }
 // g.A8 = APB (launch_split_rows_apb or a producer's split output), g.W8 = PB; K % 16 == 0, K >= 48
 void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s) {
@@ -660,6 +729,7 @@ static void launchb(const GemmArgs& a, int terms, hipStream_t s) {
     d.a = a;
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
+    d.ks = 1;
     if (terms == 6) hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 6>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 9>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
 }
@@ -669,6 +739,7 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
     d.a = a;
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
+    d.ks = 1;
     static const int ks16 = getenv("MELLOW_F32X3_KS16") ? atoi(getenv("MELLOW_F32X3_KS16")) : 1;   // k16 steps per LDS stage
     static const bool pipelined = !(getenv("MELLOW_X3_KERNEL") && getenv("MELLOW_X3_KERNEL")[0] == 'f');   // 'f' = the plain fused kernel
     if (pipelined && a.K % 16 == 0 && a.K >= 192) {      // shorter K: the 3-stage prologue costs more than it hides (K = 96: 77 vs 84 TF)
@@ -678,7 +749,9 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_p = true;
         }
-        hipLaunchKernelGGL((gemm_x3p_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+        d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
+        hipLaunchKernelGGL((gemm_x3p_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
+        if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
         return;
     }
     if (ks16 == 2 && a.K % 32 == 0) {

@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         const float4 r = *reinterpret_cast<const float4*>(g.resid + crow * g.ldr + col);
                         v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
                     }
-                    *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (g.C) *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);   // (null: only the split copy is wanted)
                     if (g.C3) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[ni][mi][4 * gq + j] = v[j];          // kept for the split store below

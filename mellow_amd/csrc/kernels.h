@@ -64,6 +64,10 @@ struct GemmArgs {
     // 64-column group P = column / 64 -- the RMS statistic of the NEXT normalisation, which the consuming GEMM applies as a row
     // scale of its accumulators (rs_*), the norm weight being folded into that GEMM's weight columns at load time.
     void* C3 = nullptr;
+    // split-K (f32x3 kernels, launches of <= 256 output tiles): workspace of up to 512 fp32 partial tiles of 128 x 128; null =
+    // never split.  The split count depends on (M, N, K) only; a second launch sums the partials in split order.
+    float* sk_ws = nullptr;
+    int sk_tiles = 0, sk_max = 0;
     float* ssq_out = nullptr;
     int ssq_parts = 0;
     // consumer side: every accumulator of row m is multiplied by 1 / sqrt(sum_p rs_ssq[m * rs_parts + p] / rs_dim + rs_eps)
@@ -242,12 +246,15 @@ void launch_stft_fft_power(const float* wpad, int fpc, int64_t clip_stride, int 
                            const float* tw2, float* power, hipStream_t s);
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s);
 // the same numbers, written pre-split in APB order (C % 16 == 0) for the x3q GEMM
+// row-map LayerNorm, output pre-split in APB order (C % 16 == 0, C <= 768; out holds roundup(M, 128) rows)
+void launch_layernorm_apb(const float* in, void* out_apb, int M, int C, const float* w, const float* b, const int32_t* row_map,
+                          int ntok, hipStream_t s);
 void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s);
 
 // ---- Swin window attention -----------------------------------------------------------------------------
 // qkv [M][3C] rows in window order; out [M][C] window order.  bias_exp [nH][64][64]; mask [nW][64][64] or null
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
-                             const float* mask, int nW, hipStream_t s);
+                             const float* mask, int nW, hipStream_t s, void* out_apb = nullptr);
 
 // ---- encoder tail -------------------------------------------------------------------------------------
 // y [n][64][768] (post final LN) -> latent [n][768] written into emb rows (n*emb_rows_stride) and im2col

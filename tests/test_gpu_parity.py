@@ -961,6 +961,48 @@ def test_norm_free_prefill_agrees_with_the_two_launch_form(synth_sd, monkeypatch
         e1.close(); e2.close()
 
 
+def test_encoder_presplit_handover_and_splitk_agree_with_the_plain_form(synth_sd, monkeypatch):
+    """f32x3 encoder, round 4 (engine_encoder.cpp run_encoder): in Swin stages 1-3 the LayerNorms, the window attention and the
+    GELU epilogue of fc1 hand their output over pre-split (APB) and qkv / proj / fc1 / fc2 run on the LDS-DMA kernel; launches of
+    <= 256 output tiles (stage 3, the patch-merging reductions, the token-semantic conv) are split along K with a fixed
+    summation order.  Against the plain form (MELLOW_ENC_APB=0, MELLOW_SPLITK=0: fp32 hand-over, register-staged kernel, no
+    split): the encoder output within 2e-5 of its maximum (both forms pass the oracle / reference taps on their own: the
+    `engine` fixture runs the default), the same tokens; and every single switch on its own as well."""
+    from mellow_amd.engine import Engine
+
+    def make(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(device=0, precision="f32x3")
+        e.load_state_dict(synth_sd)
+        for k in env:
+            monkeypatch.delenv(k)
+        return e
+
+    plain = make({"MELLOW_ENC_APB": "0", "MELLOW_SPLITK": "0"})
+    forms = {"default": make({}), "all stages": make({"MELLOW_ENC_APB": "0xFF"}), "no split-K": make({"MELLOW_SPLITK": "0"}),
+             "split-K only": make({"MELLOW_ENC_APB": "0"}), "no proj hand-over": make({"MELLOW_ENC_APB": "0x0E"})}
+    try:
+        for B in (1, 3, 32):
+            a1, a2, ids = synth.make_batch(B)
+            wav = np.concatenate([np.asarray(a1), np.asarray(a2)], 0)
+            want = plain.encode(wav).cpu().numpy()
+            tref, *_ = plain.generate(a1, a2, ids, max_len=10, stop_id=0, ignore_stop=True)
+            for name, e in forms.items():
+                got = e.encode(wav).cpu().numpy()
+                assert np.isfinite(got).all(), (name, B)
+                err = np.abs(got - want).max() / np.abs(want).max()
+                assert err < 2e-5, (name, B, err)
+                t, *_ = e.generate(a1, a2, ids, max_len=10, stop_id=0, ignore_stop=True)
+                assert np.array_equal(t, tref), (name, B)
+                again = e.encode(wav).cpu().numpy()
+                assert np.array_equal(again, got), (name, B, "not deterministic")
+    finally:
+        plain.close()
+        for e in forms.values():
+            e.close()
+
+
 def test_fork_needs_a_loaded_engine_and_shares_its_answers(engine_f32):
     from mellow_amd.engine import Engine, EngineError
     raw = Engine(device=0, precision="f32")
@@ -1284,18 +1326,36 @@ def test_degenerate_audio_matches_oracle(engine, synth_sd):
     _close(got, want, rel=5e-4, name="prefix of degenerate audio")
 
 
-def test_encoder_activations_beyond_4gib(engine):
+def test_encoder_activations_beyond_4gib(engine, synth_sd, monkeypatch):
     """BASELINE config 4 scale: 98 clips of 30 s = 686 encoder crops, so the stage-0 MLP activation (2.8 M rows x 384 floats)
     is 4.3 GB -- past the reach of a 32-bit byte offset.  Rows are batch-independent, so the last clip (whose rows lie beyond
-    the 4 GiB line) and the first must equal the same clips encoded alone, exactly."""
+    the 4 GiB line) and the first must equal the same clips encoded alone, exactly.  (Exactly = with the split-K of the f32x3
+    mode's small launches off: its split count follows the row count, so a clip encoded alone sums some dot products in a
+    different order -- 1e-6 of the output -- than the same clip inside 98; with it on, the two agree to that.)"""
+    from mellow_amd.engine import Engine
     n = 30 * spec.SAMPLE_RATE
     base = [synth.make_clip(i, n) for i in range(4)]
     wav = np.stack([base[i % 4] for i in range(98)])
     big = engine.encode(wav).cpu()
     assert torch.isfinite(big).all()
-    for idx in (0, 97):
-        alone = engine.encode(wav[idx:idx + 1]).cpu()
-        assert torch.equal(big[idx], alone[0]), idx
+    exact = engine
+    if engine.precision == "f32x3":
+        monkeypatch.setenv("MELLOW_SPLITK", "0")
+        exact = Engine(device=0, precision="f32x3")
+        exact.load_state_dict(synth_sd)
+        monkeypatch.delenv("MELLOW_SPLITK")
+        big_split, big = big, exact.encode(wav).cpu()
+        assert float((big_split - big).abs().max()) <= 2e-5 * float(big.abs().max())
+    try:
+        for idx in (0, 97):
+            alone = exact.encode(wav[idx:idx + 1]).cpu()
+            assert torch.equal(big[idx], alone[0]), idx
+            if exact is not engine:
+                split = engine.encode(wav[idx:idx + 1]).cpu()
+                assert float((split[0] - big[idx]).abs().max()) <= 2e-5 * float(big[idx].abs().max()), idx
+    finally:
+        if exact is not engine:
+            exact.close()
 
 
 def test_device_resampler_matches_host_twin(engine_f32):
