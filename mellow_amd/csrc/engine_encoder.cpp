@@ -151,12 +151,15 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
             const int32_t* map = R > kWin ? e->win_map[st][shifted ? 1 : 0] : nullptr;
             // f32x3 mode, stages in enc_apb_stages: the LayerNorms and the GELU epilogue of fc1 write their output pre-split in APB
             // order and qkv / fc1 / fc2 run on the LDS-DMA kernel (gemm_x3q_kernel); H never exists as fp32
-            const bool apb = e->f32x3_terms && ((e->enc_apb_stages >> st) & 1) && e->bf_w.count(w.qkv.p) && e->bf_w.count(w.fc1.p) &&
-                             e->bf_w.count(w.fc2.p);
+            // bit 8 + st: only the LayerNorms hand over pre-split (qkv and fc1 on the APB kernels, fc1 still writes fp32): stage 0,
+            // whose K = 96 GEMMs then run on the weight-stationary persistent kernel (gemm_x3w_kernel)
+            const bool have_pb = e->f32x3_terms && e->bf_w.count(w.qkv.p) && e->bf_w.count(w.fc1.p) && e->bf_w.count(w.fc2.p);
+            const bool apb_h = have_pb && ((e->enc_apb_stages >> st) & 1);
+            const bool apb = apb_h || (have_pb && ((e->enc_apb_stages >> (8 + st)) & 1));
             const size_t M1p = (size_t)rup(M1, 128);
             if (apb) {
                 CHK(ensure(e, e->enc_a3, (M1p * C * 6 + 3) / 4));
-                CHK(ensure(e, e->enc_h3, (M1p * 4 * C * 6 + 3) / 4));
+                if (apb_h) CHK(ensure(e, e->enc_h3, (M1p * 4 * C * 6 + 3) / 4));
                 { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n1w, w.n1b, map, N, s); }
                 CHK(run_gemm_apb(e, lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b), e->enc_a3.p, s));
             } else {
@@ -178,14 +181,15 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
             if (apb) {
                 { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n2w, w.n2b, nullptr, N, s); }
                 {
-                    GemmArgs g = lin(nullptr, C, M1, w.fc1, nullptr, 4 * C, w.fc1_b);
-                    g.act = ACT_GELU; g.C3 = e->enc_h3.p;
+                    GemmArgs g = lin(nullptr, C, M1, w.fc1, apb_h ? nullptr : e->H.p, 4 * C, w.fc1_b);
+                    g.act = ACT_GELU; g.C3 = apb_h ? e->enc_h3.p : nullptr;
                     CHK(run_gemm_apb(e, g, e->enc_a3.p, s));
                 }
                 {
-                    GemmArgs g = lin(nullptr, 4 * C, M1, w.fc2, x, C, w.fc2_b);
+                    GemmArgs g = lin(apb_h ? nullptr : e->H.p, 4 * C, M1, w.fc2, x, C, w.fc2_b);
                     g.resid = x; g.ldr = C;
-                    CHK(run_gemm_apb(e, g, e->enc_h3.p, s));
+                    if (apb_h) CHK(run_gemm_apb(e, g, e->enc_h3.p, s));
+                    else CHK(run_gemm(e, g));
                 }
             } else {
                 { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n2w, w.n2b, nullptr, N, s); }

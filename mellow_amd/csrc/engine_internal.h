@@ -193,7 +193,7 @@ struct mellow_engine {
     // the q/k/v and gate/up GEMMs run on norm-folded weights and scale their accumulators by the row statistic (run_prefill).
     // MELLOW_PREFILL_FUSE_NORM=0: the two-launch form (developer A/B), read when the engine is created.
     bool prefill_fuse_norm = true;
-    int enc_apb_stages = 0xCC;                   // f32x3 mode: Swin stages (bit st) whose LayerNorms / fc1 hand their output over pre-split (APB) to x3q GEMMs
+    int enc_apb_stages = 0x1CC;                   // f32x3 mode: Swin stages (bit st) whose LayerNorms / fc1 hand their output over pre-split (APB) to x3q GEMMs
     Buf sk_ws;                                   // split-K workspace of the f32x3 GEMMs (512 partial tiles of 128 x 128 fp32);
     bool sk_enable = false;                      // ... only launches of the encoder chain (one stream) may use it: run_encoder switches it on
     int sk_max = 8;                              // ... largest split count (MELLOW_SPLITK; < 2 = never split)

@@ -667,6 +667,149 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
     gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN, g.rs_ssq ? rs_rows : nullptr);   // (written before the main loop's barriers)
 }
 
+// ---- "x3w": the K = 96 GEMMs of Swin stage 0 (M = 4096 rows per clip), weight-stationary and persistent ---------------------
+// A 128 x 128 tile of these GEMMs is six k16 steps: 5 us of matrix work behind a prologue (first stages from memory) and in front
+// of an epilogue of 64 KB of stores, and the chip ran them at 17 us per pair of workgroups whichever kernel did it (x3p, x3q, the
+// fused K = 96 kernel).  Here a workgroup keeps ITS 64 weight columns for its whole life -- every wave holds the fragments of its
+// 32 columns for all six k16 steps in 72 VGPRs (keeping the tile in LDS instead measured the same: LDS bandwidth is not the
+// bound) -- and walks over the row panels (128 rows each) of the pre-split activation (APB) through a SIX-stage LDS-DMA ring, a
+// whole panel ahead: the ring never drains, while panel p runs, panel p + G is landing.  Each panel's 128 x 64 outputs leave
+// from its epilogue (bias from registers, optional exact-erf GELU, fp32 stores; the stores are asynchronous, the next panel's
+// MFMAs start behind them).  Four waves, wave tile 64 x 32, 72 KB of LDS: two workgroups per CU, which drift apart, so one's
+// epilogue runs under the other's MFMAs.  The same MFMAs in the same order per output element as the other x3 kernels.
+// vmcnt: the LDS-DMA loads of the four newest stages (3 per wave and stage) may stay in flight (loads complete in order among
+// loads; pending stores can only make the wait longer).
+template <bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_x3w_kernel(const GemmBDev p) {
+    constexpr int KT = 6, NST = 6;                                          // element (panel, kt) of the A stream lives in stage kt
+    constexpr int ASTAGE = 3 * 4 * 64;                                      // i32x4 per A stage: [piece][32-row tile][lane]
+    extern __shared__ __attribute__((aligned(16))) i32x4 smem_bf[];
+    i32x4* As = smem_bf;
+    const GemmArgs& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = p.gm, gn = p.gn;                                          // workgroups per column tile; 64-column tiles
+    const int L = xcd_remap((int)blockIdx.x, G * gn);
+    const int g0 = L / gn, pn = L % gn;                                     // the gn workgroups of a group walk the same panels (one L2)
+    const int panels = (g.M + 127) >> 7;
+    if (g0 >= panels) return;
+    const int n_it = (panels - g0 + G - 1) / G;
+    const uint32_t lds_a = (uint32_t)(uintptr_t)smem_bf;
+    // the weight fragments of this wave's n-tile (2 pn + wn), once: PB order [n-tile][k16][piece][lane]
+    i32x4 wf[KT][3];
+    {
+        const i32x4* wp = reinterpret_cast<const i32x4*>(g.W8) + ((int64_t)(2 * pn + wn) * KT) * 192 + lane;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) wf[kt][pc] = wp[(kt * 3 + pc) * 64];
+    }
+    // A ring: wave w carries chunks 3 w .. 3 w + 2 of the 12 of a stage
+    const char* ab = reinterpret_cast<const char*>(g.A8);
+    const uint32_t a_voff = (uint32_t)(wave * 3 * 1024 + lane * 16);
+#define X3W_ISSUE(IT, KTI)                                                                       \
+    {                                                                                            \
+        const int it_ = (IT) < n_it ? (IT) : n_it - 1;                                           \
+        const char* b_ = ab + ((int64_t)(g0 + it_ * G) * KT + (KTI)) * 12288;                    \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                            \
+            glds16(b_, a_voff + (uint32_t)(j * 1024), lds_a + (uint32_t)(((KTI) * ASTAGE) * 16 + (wave * 3 + j) * 1024)); \
+    }
+    // bias of this lane's columns (32 wn + 8 gq + 4 h .. + 3), kept in registers for every panel
+    const int h = lane >> 5;
+    const int col0 = pn * 64 + wn * 32 + 4 * h;
+    float bias[4][4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int col = col0 + 8 * gq;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && col < g.N) b4 = *reinterpret_cast<const f32x4*>(g.bias + col);
+        bias[gq][0] = b4.x; bias[gq][1] = b4.y; bias[gq][2] = b4.z; bias[gq][3] = b4.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the bias and weight-fragment loads are in
+    X3W_ISSUE(0, 0)
+    X3W_ISSUE(0, 1)
+    X3W_ISSUE(0, 2)
+    X3W_ISSUE(0, 3)
+    X3W_ISSUE(0, 4)
+    X3W_ISSUE(0, 5)
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#define X3W_FRAGS(KTI, FA)                                                                       \
+    {                                                                                            \
+        const i32x4* Ac = As + (KTI) * ASTAGE + (2 * wm) * 64 + lane;                            \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                       \
+            FA[0][pc] = Ac[(pc * 4) * 64];                                                       \
+            FA[1][pc] = Ac[(pc * 4 + 1) * 64];                                                   \
+        }                                                                                        \
+    }
+#define X3W_TERM(FA, FW, PW, PA) MELLOW_BF(FW[PW], FA[0][PA], acc[0]) MELLOW_BF(FW[PW], FA[1][PA], acc[1])
+#define X3W_MFMAS(FA, FW) X3W_TERM(FA, FW, 2, 0) X3W_TERM(FA, FW, 0, 2) X3W_TERM(FA, FW, 1, 1) X3W_TERM(FA, FW, 1, 0) X3W_TERM(FA, FW, 0, 1) X3W_TERM(FA, FW, 0, 0)
+    i32x4 fa0[2][3], fa1[2][3];
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                       // stages 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();
+    X3W_FRAGS(0, fa0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // stage 0 is free for the next panel's first element
+    // iteration (it, kt): fragments of the next element -> registers, the 12 MFMAs of this one, the LDS-DMA of the same step of
+    // the NEXT panel into the stage this one occupied, wait (all but the loads of the four newest elements), barrier
+#define X3W_ITER(KTI, FA, FAN)                                                                   \
+    {                                                                                            \
+        __builtin_amdgcn_s_setprio(2);                                                           \
+        X3W_FRAGS(((KTI) + 1) % KT, FAN)                                                         \
+        X3W_MFMAS(FA, wf[KTI])                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            if (i_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        X3W_ISSUE(it + 1, KTI)                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_s_barrier();                                                            \
+    }
+    for (int it = 0; it < n_it; ++it) {
+        X3W_ITER(0, fa0, fa1)
+        X3W_ITER(1, fa1, fa0)
+        X3W_ITER(2, fa0, fa1)
+        X3W_ITER(3, fa1, fa0)
+        X3W_ITER(4, fa0, fa1)
+        X3W_ITER(5, fa1, fa0)
+        // epilogue of panel g0 + it * G: lane owns row (lane % 32) of each of its two 32-row tiles
+        const int64_t prow = (int64_t)(g0 + it * G) * 128 + wm * 64 + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int64_t m = prow + mi * 32;
+            if (m < g.M) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = col0 + 8 * gq;
+                    if (col < g.N) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = acc[mi][4 * gq + j] + bias[gq][j];
+                            if (GELU) v[j] = gelu_erf(v[j]);
+                        }
+                        *reinterpret_cast<f32x4*>(g.C + m * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the clamped re-loads behind the last panel
+#undef X3W_ISSUE
+#undef X3W_FRAGS
+#undef X3W_TERM
+#undef X3W_MFMAS
+#undef X3W_ITER
+}
+
 #undef MELLOW_BF
 
 // A fp32 [M][lda] -> APB: i32x4 index ((panel * K/16 + kt) * 12 + piece * 4 + tile) * 64 + lane, row = panel * 128 + tile * 32
@@ -713,8 +856,32 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
     if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
 }
+// K = 96, plain LINEAR epilogue (bias, optional GELU, fp32 output): the weight-stationary persistent kernel
+static bool x3w_fits(const GemmArgs& a) {
+    static const bool off = getenv("MELLOW_X3W") && getenv("MELLOW_X3W")[0] == '0';
+    return !off && a.epi == EPI_LINEAR && a.K == 96 && a.M >= 8192 && a.C && !a.C3 && !a.resid && !a.crow_map && !a.rs_ssq &&
+           (a.act == ACT_NONE || a.act == ACT_GELU) && a.N % 4 == 0;
+}
+static void launchw(const GemmArgs& a, hipStream_t s) {
+    GemmBDev d;
+    d.a = a;
+    d.gn = (a.Nw + 63) / 64;
+    const int panels = (a.M + 127) / 128;
+    d.gm = 512 / d.gn < panels ? 512 / d.gn : panels;                      // workgroups per column tile (two per CU in all)
+    d.ks = 1;
+    const size_t lds = (size_t)(6 * (3 * 4 * 64)) * 16;                                 // 72 KiB
+    static bool attr_w = false;
+    if (!attr_w) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_w = true;
+    }
+    if (a.act == ACT_GELU) hipLaunchKernelGGL((gemm_x3w_kernel<true>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    else hipLaunchKernelGGL((gemm_x3w_kernel<false>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+}
 // g.A8 = APB (launch_split_rows_apb or a producer's split output), g.W8 = PB; K % 16 == 0, K >= 48
 void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s) {
+    if (x3w_fits(a)) return launchw(a, s);
     switch (a.epi) {
         case EPI_LINEAR: launchq<EPI_LINEAR>(a, s); break;
         case EPI_SWIGLU: launchq<EPI_SWIGLU>(a, s); break;

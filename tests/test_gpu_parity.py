@@ -962,10 +962,11 @@ def test_norm_free_prefill_agrees_with_the_two_launch_form(synth_sd, monkeypatch
 
 
 def test_encoder_presplit_handover_and_splitk_agree_with_the_plain_form(synth_sd, monkeypatch):
-    """f32x3 encoder, round 4 (engine_encoder.cpp run_encoder): in Swin stages 1-3 the LayerNorms, the window attention and the
-    GELU epilogue of fc1 hand their output over pre-split (APB) and qkv / proj / fc1 / fc2 run on the LDS-DMA kernel; launches of
-    <= 256 output tiles (stage 3, the patch-merging reductions, the token-semantic conv) are split along K with a fixed
-    summation order.  Against the plain form (MELLOW_ENC_APB=0, MELLOW_SPLITK=0: fp32 hand-over, register-staged kernel, no
+    """f32x3 encoder, round 4 (engine_encoder.cpp run_encoder): in Swin stages 2-3 the LayerNorms, the window attention and the
+    GELU epilogue of fc1 hand their output over pre-split (APB) and qkv / proj / fc1 / fc2 run on the LDS-DMA kernel; in stage 0
+    the LayerNorms hand over pre-split and the K = 96 GEMMs qkv / fc1 run on the weight-stationary persistent kernel
+    (gemm_x3w_kernel; B = 32 here is what reaches its M >= 8192 rows); launches of <= 256 output tiles (stage 3 fc2, the
+    token-semantic conv, small batches) are split along K with a fixed summation order.  Against the plain form (MELLOW_ENC_APB=0, MELLOW_SPLITK=0: fp32 hand-over, register-staged kernel, no
     split): the encoder output within 2e-5 of its maximum (both forms pass the oracle / reference taps on their own: the
     `engine` fixture runs the default), the same tokens; and every single switch on its own as well."""
     from mellow_amd.engine import Engine
@@ -981,7 +982,9 @@ def test_encoder_presplit_handover_and_splitk_agree_with_the_plain_form(synth_sd
 
     plain = make({"MELLOW_ENC_APB": "0", "MELLOW_SPLITK": "0"})
     forms = {"default": make({}), "all stages": make({"MELLOW_ENC_APB": "0xFF"}), "no split-K": make({"MELLOW_SPLITK": "0"}),
-             "split-K only": make({"MELLOW_ENC_APB": "0"}), "no proj hand-over": make({"MELLOW_ENC_APB": "0x0E"})}
+             "split-K only": make({"MELLOW_ENC_APB": "0"}), "no proj hand-over": make({"MELLOW_ENC_APB": "0x0E"}),
+             "stage 0 without the weight-stationary kernel": make({"MELLOW_ENC_APB": "0xCC"}),
+             "stage 0 pre-split on the tile kernels": make({"MELLOW_X3W": "0"})}
     try:
         for B in (1, 3, 32):
             a1, a2, ids = synth.make_batch(B)

@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16  # noqa: E402
 
-NAMES = ("gemm_x3q_kernel", "gemm_x3p_kernel", "gemm_bf16x3f_kernel", "gemm_f32_kernel", "prefill_attention_x3_kernel",
+NAMES = ("gemm_x3q_kernel", "gemm_x3p_kernel", "gemm_x3w_kernel", "gemm_bf16x3f_kernel", "gemm_f32_kernel", "prefill_attention_x3_kernel",
          "prefill_attention_kernel", "window_attention_mfma_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(sys.argv[1])):
