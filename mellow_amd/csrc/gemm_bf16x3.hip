@@ -679,6 +679,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
 // epilogue runs under the other's MFMAs.  The same MFMAs in the same order per output element as the other x3 kernels.
 // vmcnt: the LDS-DMA loads of the four newest stages (3 per wave and stage) may stay in flight (loads complete in order among
 // loads; pending stores can only make the wait longer).
+#ifndef MELLOW_X3W_ABL
+#define MELLOW_X3W_ABL 0       // developer ablation (tools/ab_build.sh -DMELLOW_X3W_ABL=bits): 1 no output stores, 2 no MFMAs, 4 output stored column-tile-major (wrong results, timing only)
+#endif
 template <bool GELU>
 __global__ __launch_bounds__(256, 2) void gemm_x3w_kernel(const GemmBDev p) {
     constexpr int KT = 6, NST = 6;                                          // element (panel, kt) of the A stream lives in stage kt
@@ -748,59 +751,69 @@ __global__ __launch_bounds__(256, 2) void gemm_x3w_kernel(const GemmBDev p) {
     }
 #define X3W_TERM(FA, FW, PW, PA) MELLOW_BF(FW[PW], FA[0][PA], acc[0]) MELLOW_BF(FW[PW], FA[1][PA], acc[1])
 #define X3W_MFMAS(FA, FW) X3W_TERM(FA, FW, 2, 0) X3W_TERM(FA, FW, 0, 2) X3W_TERM(FA, FW, 1, 1) X3W_TERM(FA, FW, 1, 0) X3W_TERM(FA, FW, 0, 1) X3W_TERM(FA, FW, 0, 0)
-    i32x4 fa0[2][3], fa1[2][3];
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                       // stages 0 and 1 have landed
+    // a STEP is two k16 tiles (24 MFMAs per barrier: with one tile per barrier the kernel ran at 146 / 199 us, the barrier and the
+    // fragment-read latency of a 12-MFMA step being as long as its MFMAs); fragment sets are double-buffered per step
+    i32x4 fa0[2][2][3], fa1[2][2][3];                                       // [k16 tile of the step][m-tile][piece]
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        // steps 0 and 1 (stages 0..3) have landed
     __builtin_amdgcn_s_barrier();
-    X3W_FRAGS(0, fa0)
+    X3W_FRAGS(0, fa0[0])
+    X3W_FRAGS(1, fa0[1])
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // stage 0 is free for the next panel's first element
-    // iteration (it, kt): fragments of the next element -> registers, the 12 MFMAs of this one, the LDS-DMA of the same step of
-    // the NEXT panel into the stage this one occupied, wait (all but the loads of the four newest elements), barrier
-#define X3W_ITER(KTI, FA, FAN)                                                                   \
+    __builtin_amdgcn_s_barrier();                                           // stages 0, 1 are free for the next panel's first step
+    // iteration (it, step): fragments of the next step -> registers, the 24 MFMAs of this one, the LDS-DMA of the same step of the
+    // NEXT panel into the two stages this one occupied, wait (all but the six loads just issued), barrier
+#define X3W_ITER(ST, FA, FAN)                                                                    \
     {                                                                                            \
         __builtin_amdgcn_s_setprio(2);                                                           \
-        X3W_FRAGS(((KTI) + 1) % KT, FAN)                                                         \
-        X3W_MFMAS(FA, wf[KTI])                                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                      \
+        X3W_FRAGS((2 * (ST) + 2) % KT, FAN[0])                                                   \
+        X3W_FRAGS((2 * (ST) + 3) % KT, FAN[1])                                                   \
+        if (!(MELLOW_X3W_ABL & 2)) {                                                             \
+            X3W_MFMAS(FA[0], wf[2 * (ST)])                                                       \
+            X3W_MFMAS(FA[1], wf[2 * (ST) + 1])                                                   \
+        } else {                                                                                 \
+            acc[0][0] += __int_as_float(FA[0][0][0][0] ^ FA[1][1][2][3]);                        \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                      \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
-            if (i_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+            if (i_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        X3W_ISSUE(it + 1, KTI)                                                                   \
+        X3W_ISSUE(it + 1, 2 * (ST))                                                              \
+        X3W_ISSUE(it + 1, 2 * (ST) + 1)                                                          \
         __builtin_amdgcn_s_setprio(0);                                                           \
-        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                             \
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                              \
         __builtin_amdgcn_s_barrier();                                                            \
     }
-    for (int it = 0; it < n_it; ++it) {
-        X3W_ITER(0, fa0, fa1)
-        X3W_ITER(1, fa1, fa0)
-        X3W_ITER(2, fa0, fa1)
-        X3W_ITER(3, fa1, fa0)
-        X3W_ITER(4, fa0, fa1)
-        X3W_ITER(5, fa1, fa0)
-        // epilogue of panel g0 + it * G: lane owns row (lane % 32) of each of its two 32-row tiles
-        const int64_t prow = (int64_t)(g0 + it * G) * 128 + wm * 64 + (lane & 31);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int64_t m = prow + mi * 32;
-            if (m < g.M) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int col = col0 + 8 * gq;
-                    if (col < g.N) {
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = acc[mi][4 * gq + j] + bias[gq][j];
-                            if (GELU) v[j] = gelu_erf(v[j]);
-                        }
-                        *reinterpret_cast<f32x4*>(g.C + m * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-        }
+    // epilogue of panel g0 + it * G: lane owns row (lane % 32) of each of its two 32-row tiles
+#define X3W_EPILOGUE()                                                                           \
+    {                                                                                            \
+        const int64_t prow = (int64_t)(g0 + it * G) * 128 + wm * 64 + (lane & 31);               \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                       \
+            const int64_t m = prow + mi * 32;                                                    \
+            if (m < g.M) {                                                                       \
+                _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                               \
+                    const int col = col0 + 8 * gq;                                               \
+                    if (col < g.N) {                                                             \
+                        float v[4];                                                              \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
+                            v[j] = acc[mi][4 * gq + j] + bias[gq][j];                            \
+                            if (GELU) v[j] = gelu_erf(v[j]);                                     \
+                        }                                                                        \
+                        if (MELLOW_X3W_ABL & 4) *reinterpret_cast<f32x4*>(g.C + ((int64_t)(pn % (g.N >> 6)) * g.M + m) * 64 + (col & 63)) = f32x4{v[0], v[1], v[2], v[3]}; \
+                        else if (!(MELLOW_X3W_ABL & 1) || v[0] == 1.2345f) *reinterpret_cast<f32x4*>(g.C + m * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]}; \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;                     \
+        }                                                                                        \
+    }
+    // three steps per panel: the two fragment sets swap roles from one panel to the next
+#define X3W_PANEL(A0, A1) X3W_ITER(0, A0, A1) X3W_ITER(1, A1, A0) X3W_ITER(2, A0, A1) X3W_EPILOGUE()
+    for (int it = 0; it < n_it;) {
+        X3W_PANEL(fa0, fa1)
+        if (++it >= n_it) break;
+        X3W_PANEL(fa1, fa0)
+        ++it;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the clamped re-loads behind the last panel
 #undef X3W_ISSUE
@@ -808,6 +821,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3w_kernel(const GemmBDev p) {
 #undef X3W_TERM
 #undef X3W_MFMAS
 #undef X3W_ITER
+#undef X3W_EPILOGUE
+#undef X3W_PANEL
 }
 
 #undef MELLOW_BF
