@@ -14,6 +14,57 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     // rs_rows (optional): the row scales of this workgroup's BM rows, computed by the kernel BEFORE its main loop (LDS)
     // ---- epilogue: lane owns row m_local = lane&31 of each m-tile, columns 8g + 4h + (0..3) ----------
     const int h = lane >> 5;
+    // Everything the epilogue READS from memory is fetched up front, in one round of latency.  Left inside the store loops the
+    // loads are serialised by the compiler behind the stores they might alias (the residual IS the output buffer of the in-place
+    // GEMMs): sixteen load -> add -> store rounds per lane, 15-20 us of a 60 us o_proj launch (round 4).
+    float4 pre_a[2][2][4], pre_b[2][4];         // residual (or rotary cos / sin) per output quad; bias per column quad
+    int64_t pre_crow[2];
+    if constexpr (EPI == EPI_LINEAR) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
+            pre_crow[mi] = m;
+            if (m < g.M && g.crow_map) pre_crow[mi] = (int64_t)(m / g.rows_in) * g.rows_out + g.crow_map[m % g.rows_in];
+        }
+        if (g.bias) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = pn * BN + wn * 64 + ni * 32 + 8 * gq + 4 * h;
+                    pre_b[ni][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (col < g.N) pre_b[ni][gq] = *reinterpret_cast<const float4*>(g.bias + col);
+                }
+        }
+        if (g.resid) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int col = pn * BN + wn * 64 + ni * 32 + 8 * gq + 4 * h;
+                        pre_a[mi][ni][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < g.M && col < g.N) pre_a[mi][ni][gq] = *reinterpret_cast<const float4*>(g.resid + pre_crow[mi] * g.ldr + col);
+                    }
+            }
+        }
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        const int P = pn * WN + wn;
+        if (P < g.q_heads + g.kv_heads) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
+                const int t = (m < g.M ? m : g.M - 1) % g.T;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    pre_a[mi][0][gq] = *reinterpret_cast<const float4*>(g.rope_cos + (int64_t)t * 32 + 8 * gq + 4 * h);
+                    pre_a[mi][1][gq] = *reinterpret_cast<const float4*>(g.rope_sin + (int64_t)t * 32 + 8 * gq + 4 * h);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int m = pm * BM + wm * 64 + mi * 32 + (lane & 31);
@@ -36,8 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                 for (int q = 0; q < 16; ++q) acc[ni][mi][q] *= r;
         }
         if constexpr (EPI == EPI_LINEAR) {
-            int64_t crow = m;
-            if (g.crow_map) crow = (int64_t)(m / g.rows_in) * g.rows_out + g.crow_map[m % g.rows_in];
+            const int64_t crow = pre_crow[mi];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -48,7 +98,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * gq + j];
                     if (g.bias) {
-                        const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+                        const float4 b = pre_b[ni][gq];
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if (g.act == ACT_GELU) {
@@ -59,7 +109,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]);
                     }
                     if (g.resid) {
-                        const float4 r = *reinterpret_cast<const float4*>(g.resid + crow * g.ldr + col);
+                        const float4 r = pre_a[mi][ni][gq];
                         v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
                     }
                     if (g.C) *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);   // (null: only the split copy is wanted)
@@ -152,8 +202,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     // P = head slot: [0,q_heads) query heads, then kv_heads key heads, then kv_heads value heads
                     const int b = m / g.T, t = m % g.T;
                     if (P < g.q_heads + g.kv_heads) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(g.rope_cos + (int64_t)t * 32 + i0);
-                        const float4 s4 = *reinterpret_cast<const float4*>(g.rope_sin + (int64_t)t * 32 + i0);
+                        const float4 c4 = pre_a[mi][0][gq], s4 = pre_a[mi][1][gq];        // (t, i0 = 8 gq + 4 h: fetched up front)
                         const float c[4] = {c4.x, c4.y, c4.z, c4.w};
                         const float sn[4] = {s4.x, s4.y, s4.z, s4.w};
                         float o1[4], o2[4];
