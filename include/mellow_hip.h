@@ -224,7 +224,9 @@ int         mellow_set_graph(mellow_engine_t* e, int on);
  *     reports): fp32 GEMMs on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into three bf16 terms, the six largest
  *     partial products (the rest is < 2^-23 |a*b|) are accumulated in fp32: fp32-accurate (error against fp64 measured <= the
  *     fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32.  Every engine-level parity test (tolerances against the
- *     reference's fp32 outputs, exact greedy tokens) runs in this mode and in MELLOW_PRECISION_F32. */
+ *     reference's fp32 outputs, exact greedy tokens) runs in this mode and in MELLOW_PRECISION_F32.  In this mode the last bits
+ *     of an example's activations may depend on how many examples the call holds: encoder launches of few output tiles are split
+ *     along K (a fixed summation order per launch shape; MELLOW_SPLITK=0 in the environment turns it off). */
 #define MELLOW_PRECISION_F32 0
 #define MELLOW_PRECISION_FP8 1
 #define MELLOW_PRECISION_F32X3 2
