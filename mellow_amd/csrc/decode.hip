@@ -22,6 +22,10 @@
 //     consumers in a fixed order.
 #include "common.h"
 #include "kernels.h"
+#include <cstdio>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace mellow {
 
@@ -872,6 +876,310 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
 }
 
 // ----------------------------------------------------------------------------------------------------
+// f32x3 mode (the engine's default): the decode GEMMs on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand value is
+// the EXACT sum of three bf16 pieces (split3, common.h: the same split as the prefill GEMMs of gemm_bf16x3.hip), formed here
+// IN REGISTERS right after the fp32 fragments have landed -- the weights stay 4 bytes per value in HBM, the activations stay
+// fp32 between launches -- and the six largest partial products run on v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD for
+// K = 16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same K), smallest first, fp32 accumulation.  No repacking:
+// a lane's float4 of k-tile t and of k-tile t + 1 are the eight k positions of its bf16 operand; A (weights, P-layout) and
+// B (activations, F32-layout) agree on which k a slot holds (lane half h of tile t: k = 8t + 4h + j), which is all the
+// contraction needs (the e4m3 form above pairs its tiles the same way).
+// Row blocks: one workgroup serves EVERY 32-row block of the batch with the weight fragments it split once (the fp32 kernels
+// above replicate the grid per row block and re-stream the weights).
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_pair(float4 a, float4 b, i32x4& p0, i32x4& p1, i32x4& p2) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    split8(v, p0, p1, p2);
+}
+#define MELLOW_BF16(W, X, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), ACC, 0, 0, 0)
+// six of the nine partial products, smallest first (pieces: 0 = leading, 2 = trailing; dropped: (1,2), (2,1), (2,2) < 2^-23 |w x|)
+__device__ __forceinline__ f32x16 mma6(f32x16 acc, const i32x4 (&w)[3], const i32x4 (&x)[3]) {
+    MELLOW_BF16(w[2], x[0], acc);
+    MELLOW_BF16(w[0], x[2], acc);
+    MELLOW_BF16(w[1], x[1], acc);
+    MELLOW_BF16(w[1], x[0], acc);
+    MELLOW_BF16(w[0], x[1], acc);
+    MELLOW_BF16(w[0], x[0], acc);
+    return acc;
+}
+
+// Pre-split activations ("F3" layouts): where ONE launch produces an activation that MANY workgroups of the next launch
+// multiply, the producer also stores it as bf16 triples in the consumer's fragment order, so that the split is paid once per
+// value instead of once per consuming workgroup (the lm_head has 1536 of them).  6 bytes per value instead of 4.
+//   F3-32 (B operand of v_mfma_f32_32x32x16_bf16; K8 = K / 8 tiles, pairs T = K / 16):
+//       16-byte slot ((rb * K/16 + T) * 3 + piece) * 64 + lane,  lane = m % 32 + 32 h;  element e of the slot:
+//       k = 16 T + 4 h + e (e < 4),  16 T + 8 + 4 h + (e - 4)  -- the lane's float4 of k-tile 2T and of k-tile 2T + 1 (F32-layout)
+//   F3-16 (B operand of v_mfma_f32_16x16x32_bf16; k16 tiles t, pairs T = K / 32, row halves mh):
+//       slot (((rb * K/32 + T) * 2 + mh) * 3 + piece) * 64 + lane,  lane = m % 16 + 16 q;  k = 32 T + 4 q + e (e < 4),
+//       32 T + 16 + 4 q + (e - 4)  -- the lane's float4 of k16-tile 2T and 2T + 1 (F16-layout)
+// A producer thread that owns four consecutive k of one row stores 8 bytes (4 bf16) per piece: element half eh of the slot.
+__device__ __forceinline__ void f3_store4(void* base, int64_t slot0, int eh, float4 y) {
+    __bf16 h[4], m[4], l[4];
+    split3(y.x, h[0], m[0], l[0]); split3(y.y, h[1], m[1], l[1]); split3(y.z, h[2], m[2], l[2]); split3(y.w, h[3], m[3], l[3]);
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    uint2* p = reinterpret_cast<uint2*>(base) + slot0 * 2 + eh;
+    p[0] = __builtin_bit_cast(uint2, bf16x4{h[0], h[1], h[2], h[3]});
+    p[64 * 2] = __builtin_bit_cast(uint2, bf16x4{m[0], m[1], m[2], m[3]});
+    p[128 * 2] = __builtin_bit_cast(uint2, bf16x4{l[0], l[1], l[2], l[3]});
+}
+// slot of piece 0 for (row m of block rb, columns k .. k + 3, k % 4 == 0); *eh = element half
+__device__ __forceinline__ int64_t f3_32_slot(int rb, int KP, int m, int k, int* eh) {
+    *eh = (k >> 3) & 1;
+    return ((int64_t)rb * KP + (k >> 4)) * 3 * 64 + m + 32 * ((k >> 2) & 1);
+}
+__device__ __forceinline__ int64_t f3_16_slot(int rb, int KP, int m, int k, int* eh) {
+    *eh = (k >> 4) & 1;
+    return (((int64_t)rb * KP + (k >> 5)) * 2 + (m >> 4)) * 3 * 64 + (m & 15) + 16 * ((k >> 2) & 3);
+}
+
+#ifndef MELLOW_LM3_WAVES
+#define MELLOW_LM3_WAVES 12
+#endif
+constexpr int LM3_WAVES = MELLOW_LM3_WAVES;
+// K4x  lm_head, f32x3 form.  grid (n-tiles), LM3_WAVES waves x (72 / LM3_WAVES) k-tiles; loops over the row blocks.
+// XPRE: the activations arrive pre-split (F3-32, written by the final norm); otherwise they are split here (taps on caller rows)
+template <bool BLK, bool XPRE>
+__global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
+                                                                    int N, int RB_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
+    __shared__ __attribute__((aligned(16))) float red[LM3_WAVES * 16 * 64];
+    constexpr int KPW = 72 / LM3_WAVES, PP = KPW / 2;
+    static_assert(KPW * LM3_WAVES == 72 && PP * 2 == KPW, "waves must divide the 72 k-tiles into whole pairs");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x;
+    const int k8_0 = wave * KPW;
+    const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
+    float4 w[KPW], x[XPRE ? 1 : KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) w[i] = ldg_nt(reinterpret_cast<const float4*>(Wp) + wslot + i * 64);
+    int rb = 0;
+    if (BLK) { while (rb < RB_p && a.blk_live[rb] == 0) ++rb; }          // first live block (workgroup-uniform)
+    if (rb >= RB_p) return;
+    i32x4 xq[PP][3], xn[XPRE ? PP : 1][3];
+    const i32x4* X3 = reinterpret_cast<const i32x4*>(XF) + (int64_t)wave * PP * 3 * 64 + lane;      // XPRE: XF = the F3-32 image
+    if constexpr (XPRE) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xq[p][c] = X3[((int64_t)rb * 36 * 3 + p * 3 + c) * 64];
+    } else {
+        const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    i32x4 wp[PP][3];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+    while (rb < RB_p) {
+        if constexpr (!XPRE) {
+#pragma unroll
+            for (int p = 0; p < PP; ++p) split_pair(x[2 * p], x[2 * p + 1], xq[p][0], xq[p][1], xq[p][2]);
+        }
+        int nrb = rb + 1;
+        if (BLK) { while (nrb < RB_p && a.blk_live[nrb] == 0) ++nrb; }
+        if (nrb < RB_p) {                   // the next block's fragments travel while this one is multiplied
+            if constexpr (XPRE) {
+#pragma unroll
+                for (int p = 0; p < PP; ++p)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) xn[p][c] = X3[((int64_t)nrb * 36 * 3 + p * 3 + c) * 64];
+            } else {
+                const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)nrb * 72 + k8_0) * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) acc = mma6(acc, wp[p], xq[p]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        const bool epi = tid < 256;
+        const int mm = tid & 31, hh = (tid >> 5) & 1, gq = (tid >> 6) & 3;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * gq + j;
+            float sacc = red[r * 64 + mm + 32 * hh];
+#pragma unroll
+            for (int wv = 1; wv < LM3_WAVES; ++wv) sacc += red[(wv * 16 + r) * 64 + mm + 32 * hh];      // fixed order
+            v[j] = sacc;
+        }
+        const int n = nt * 32 + 8 * gq + 4 * hh;
+        const int64_t row = (int64_t)rb * 32 + mm;
+        if (epi && a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        // best (value, lowest index) of this 32-column tile per row (torch.argmax tie rule)
+        __syncthreads();
+        float bv = v[0];
+        int bi = n;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (arg_better(v[j], n + j, bv, bi)) { bv = v[j]; bi = n + j; }
+        if (epi) {
+            red[tid] = bv;
+            reinterpret_cast<int*>(red)[256 + tid] = bi;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float best = red[tid];
+            int idx = reinterpret_cast<int*>(red)[256 + tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                const float ov = red[tid + 32 * q];
+                const int oi = reinterpret_cast<int*>(red)[256 + tid + 32 * q];
+                if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
+            }
+            const int64_t o = ((int64_t)rb * 32 + tid) * (N >> 5) + nt;
+            a.cand_val[o] = best;
+            a.cand_idx[o] = idx;
+        }
+        if (nrb < RB_p) __syncthreads();          // the next block's partial sums reuse `red`
+        if constexpr (XPRE) {
+            if (nrb < RB_p) {
+#pragma unroll
+                for (int p = 0; p < PP; ++p)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) xq[p][c] = xn[p][c];
+            }
+        }
+        rb = nrb;
+    }
+    kspan(a.dbg_seq, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// K4y  lm_head, f32x3 form, as a streaming GEMM: one WAVE owns a 32-row n-tile over the WHOLE K = 576 (no split-K, no LDS
+//      reduction), a workgroup = H3_NW waves = H3_NW consecutive n-tiles, and the pre-split activations (F3-32, written by the
+//      final norm) of up to G row blocks go through LDS in K-chunks of H3_CP pairs, shared by the waves.  The weights are
+//      streamed ONCE per step whatever the batch (the fp32 kernel above re-reads them per row block and every 32-row tile
+//      re-reads x: at B = 128 that is 4 x 113 MB of weights and 0.45 GB of activations through the L2s), split to bf16 triples
+//      in registers once per chunk and used for all G row blocks.  Rows beyond G blocks: further passes.
+//      The arg-max candidates of a tile are formed from the accumulators directly (a wave holds all 32 columns of its rows).
+// ----------------------------------------------------------------------------------------------------
+#ifndef MELLOW_H3_NW
+#define MELLOW_H3_NW 8
+#endif
+#ifndef MELLOW_H3_D1
+#define MELLOW_H3_D1 1
+#endif
+#ifndef MELLOW_H3_D2
+#define MELLOW_H3_D2 1
+#endif
+#ifndef MELLOW_H3_D4
+#define MELLOW_H3_D4 1
+#endif
+constexpr int H3_NW = MELLOW_H3_NW, H3_CP = 3, H3_NC = 36 / H3_CP;
+// D = chunks of weights a wave keeps in flight ahead of the one it multiplies (registers): what hides the HBM latency behind the
+// matrix work of a chunk -- 0.24 us per row block, against 2-3 us of latency under load
+template <int G, int D, bool BLK>
+__global__ __launch_bounds__(H3_NW * 64) void dec_head3_kernel(const float* __restrict__ Wp, const i32x4* __restrict__ X3, int K8p, int N,
+                                                               int RB_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
+    extern __shared__ __attribute__((aligned(16))) i32x4 xs[];        // [2 stages][G][H3_CP][3][64]
+    constexpr int STAGE = G * H3_CP * 3 * 64;                          // 16-byte slots per stage
+    constexpr int FILL = (STAGE + H3_NW * 64 - 1) / (H3_NW * 64);     // slots per thread per chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * H3_NW + wave;
+    const float4* wbase = reinterpret_cast<const float4*>(Wp) + (int64_t)nt * K8p * 64 + lane;
+    for (int rb0 = 0; rb0 < RB_p; rb0 += G) {
+        const int gn = min(G, RB_p - rb0);
+        f32x16 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        // chunk c of x for the gn row blocks: slot i of the stage = (g, p, piece, lane) -> X3[((rb0 + g) * 36 + c * CP + p) * 3 + piece][lane]
+        auto x_src = [&](int c, int i) {
+            const int g = i / (H3_CP * 3 * 64), rest = i % (H3_CP * 3 * 64);
+            return X3 + (((int64_t)(rb0 + (g < gn ? g : 0)) * 36 + c * H3_CP) * 3) * 64 + rest;
+        };
+        float4 wn[D][2 * H3_CP];
+        i32x4 xf[FILL];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + (d * 2 * H3_CP + i) * 64);
+#pragma unroll
+        for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) xs[i] = *x_src(0, i); }
+        static_assert(H3_NC % D == 0, "the chunk loop is unrolled by the prefetch depth");
+        for (int c0 = 0; c0 < H3_NC; c0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int c = c0 + d;
+                __syncthreads();              // stage c % 2 is complete; every read of stage (c + 1) % 2 (iteration c - 1) is done
+                float4 w[2 * H3_CP];
+#pragma unroll
+                for (int i = 0; i < 2 * H3_CP; ++i) w[i] = wn[d][i];
+                if (c + D < H3_NC) {
+#pragma unroll
+                    for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + ((c + D) * 2 * H3_CP + i) * 64);
+                }
+                if (c + 1 < H3_NC) {
+#pragma unroll
+                    for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) xf[j] = *x_src(c + 1, i); }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // (keeps the next chunks' loads where they are: ahead of this chunk's work)
+                i32x4 wp[H3_CP][3];
+#pragma unroll
+                for (int p = 0; p < H3_CP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+                const i32x4* st = xs + (c & 1) * STAGE + lane;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (g < gn) {
+#pragma unroll
+                        for (int p = 0; p < H3_CP; ++p) {
+                            const i32x4 xq[3] = {st[((g * H3_CP + p) * 3 + 0) * 64], st[((g * H3_CP + p) * 3 + 1) * 64], st[((g * H3_CP + p) * 3 + 2) * 64]};
+                            acc[g] = mma6(acc[g], wp[p], xq);
+                        }
+                    }
+                }
+                if (c + 1 < H3_NC) {
+                    i32x4* dst = xs + ((c + 1) & 1) * STAGE;
+#pragma unroll
+                    for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) dst[i] = xf[j]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: D[n = 8 (r / 4) + 4 h + r % 4][m = lane % 32], h = lane / 32
+        const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g < gn && !(BLK && a.blk_live[rb0 + g] == 0)) {
+                const int64_t row = (int64_t)(rb0 + g) * 32 + m;
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nt * 32 + 8 * q + 4 * h;
+                    if (a.logits) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (arg_better(acc[g][4 * q + j], n + j, bv, bi)) { bv = acc[g][4 * q + j]; bi = n + j; }
+                }
+                // the other half-wave holds the row's other 16 columns
+                auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+                auto ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+                const float ov = __uint_as_float(h ? rv[0] : rv[1]);
+                const int oi = (int)(h ? ri[0] : ri[1]);
+                if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                if (h == 0) {
+                    const int64_t o = row * (N >> 5) + nt;
+                    a.cand_val[o] = bv;
+                    a.cand_idx[o] = bi;
+                }
+            }
+        }
+        if (rb0 + G < RB_p) __syncthreads();          // the next pass refills stage 0
+    }
+    kspan(a.dbg_seq, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // K4b gate/up projection + SwiGLU on 16-row weight tiles.  grid (192 n16-tiles, RB), 4 waves x 9 k16-tiles,
 //     v_mfma_f32_16x16x4_f32; W = folded gate/up in P16-layout, tile t = gate[8t..8t+7] | up[8t..8t+7];
 //     X = x_mid in F16-layout.  192 workgroups x (36 KB of W + 72 KB of X).
@@ -1225,7 +1533,13 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __rest
         float4 y;
         y.x = __fmul_rn(wv.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(wv.y, __fmul_rn(v.y, r));
         y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
-        reinterpret_cast<float4*>(a.xnF)[fi] = y;
+        if (a.xn3) {                       // f32x3 lm_head: pre-split, F3-32
+            int eh;
+            const int64_t sl = f3_32_slot(b >> 5, 36, b & 31, xi * 4, &eh);
+            f3_store4(a.xn3, sl, eh, y);
+        } else {
+            reinterpret_cast<float4*>(a.xnF)[fi] = y;
+        }
     }
     kspan(a.dbg_seq, 1);
 }
@@ -1386,6 +1700,20 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel function AND per device (an engine per GPU, pools of host threads):
+// remembered per (function, device) under a lock; the attribute call itself is cheap but not free on a per-step path.
+static void set_max_lds(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({fn, dev}).second) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) fprintf(stderr, "mellow: hipFuncSetAttribute(max dynamic LDS %zu) failed: %s\n", bytes, hipGetErrorString(e));
+    }
+}
 // BLK = per-row-block early exit compiled in (a.blk_live != null); W8 = e4m3 weights (wscale != null): chosen on the host
 #define MELLOW_LAUNCH_BLK(KERNEL, GRID, BLOCK, ...)                                                               \
     do {                                                                                                         \
@@ -1536,6 +1864,28 @@ void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipSt
     }
 }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale) {
+    if ((a.x3 & DEC_X3_HEAD) && !wscale && a.xn3 && (vocab / 32) % H3_NW == 0) {
+        // f32x3 mode, activations pre-split by the final norm: the streaming form (weights read once for every row block)
+        const dim3 grid(vocab / 32 / H3_NW), block(H3_NW * 64);
+        const i32x4* X3 = reinterpret_cast<const i32x4*>(a.xn3);
+#define MELLOW_H3(GV, DV)                                                                                                 \
+        do {                                                                                                              \
+            const size_t lds = (size_t)2 * GV * H3_CP * 3 * 64 * 16;                                                      \
+            if (a.blk_live) { set_max_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, true>), lds);           \
+                              hipLaunchKernelGGL((dec_head3_kernel<GV, DV, true>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
+            else { set_max_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
+                   hipLaunchKernelGGL((dec_head3_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
+        } while (0)
+        if (a.RB == 1) MELLOW_H3(1, MELLOW_H3_D1); else if (a.RB == 2) MELLOW_H3(2, MELLOW_H3_D2); else MELLOW_H3(4, MELLOW_H3_D4);
+#undef MELLOW_H3
+        return;
+    }
+    if ((a.x3 & DEC_X3_HEAD) && !wscale) {          // f32x3 mode on caller rows (taps): operands split in registers
+        const dim3 grid(vocab / 32), block(LM3_WAVES * 64);
+        if (a.blk_live) hipLaunchKernelGGL((dec_fullk3_kernel<true, false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
+        else hipLaunchKernelGGL((dec_fullk3_kernel<false, false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
+        return;
+    }
     const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
     const int mode = w8_mode(a, wscale);
     if (a.blk_live && mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 2>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);

@@ -401,6 +401,10 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
         const char* t = getenv("MELLOW_F32X3_TERMS");
         e->f32x3_terms = (t && atoi(t) == 9) ? 9 : 6;
     }
+    // f32x3 mode: the decode step's GEMM launches split their operands in registers and run on the bf16 pipe as well
+    // (decode.hip); MELLOW_DECODE_X3=<mask of DEC_X3_*> is the developer A/B (0 = the exact fp32 MFMA decode kernels)
+    const char* dx = getenv("MELLOW_DECODE_X3");
+    e->dec_x3 = mode == MELLOW_PRECISION_F32X3 ? (dx ? atoi(dx) & DEC_X3_ALL : DEC_X3_ALL) : 0;
     return 0;
 }
 
@@ -415,7 +419,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
     c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb; c->enc_apb_stages = parent->enc_apb_stages; c->sk_max = parent->sk_max;
-    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms;
+    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;
     c->bn_alpha = parent->bn_alpha; c->bn_beta = parent->bn_beta;

@@ -188,6 +188,7 @@ struct mellow_engine {
     bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (off: MELLOW_FP8_DECODE_ACT=0)
     bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (off: MELLOW_FP8_PREFILL=0, a test isolating the decode weights)
     float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
+    int dec_x3 = 0;                              // f32x3 mode: DEC_X3_* mask of the decode GEMM launches on the bf16 pipe (MELLOW_DECODE_X3=mask, developer A/B)
     int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
     // f32x3 LM prefill without RMSNorm launches: the o_proj / down GEMMs write their output pre-split + its sum of squares,
     // the q/k/v and gate/up GEMMs run on norm-folded weights and scale their accumulators by the row statistic (run_prefill).

@@ -39,7 +39,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         const size_t n_x = (size_t)Bp * 576;
         size_t off = 0;
         auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
-        const size_t o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x);
+        const size_t o_xmidF = take(n_x), o_xnewR = take(n_x), o_xnF = take(n_x * 3 / 2);      // (xnF: fp32, or its 6-byte pre-split image)
         const size_t o_dslabF = take(DEC_KC_DOWN * n_x), o_ssq1 = take((size_t)Bp * DEC_KC_QKV), o_rope = take(64);
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
         const size_t o_att = take((size_t)DEC_TS * n_x), o_aml = take((size_t)DEC_TS * 9 * Bp * 2);
@@ -58,11 +58,13 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
         a.a8 = e->fp8_decode_act ? 1 : 0;
+        a.x3 = e->dec_x3;
         a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
         a.row_of_slot = nullptr;
         // (and the logits store off: the taps mellow_lm_prefill / mellow_lm_decode_step read dlogits, generation does not)
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
+        a.xn3 = (a.x3 & DEC_X3_HEAD) && !e->head8 ? (void*)(p + o_xnF) : nullptr;
         a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
         {
             // key split of the decode attention: balanced at the END of the reserved context, rounded down to whole
@@ -437,6 +439,7 @@ int mellow_debug_dec_head(mellow_engine_t* e, const float* x, int B, int act_fp8
     a.blk_live = nullptr; a.row_of_slot = nullptr;
     a.a8 = (act_fp8 && e->head8) ? 1 : 0;
     a.xnF = a.xmidF;                                  // dec_load_rows writes the F32-layout operand there
+    a.xn3 = nullptr;                                  // (the f32x3 kernel splits these rows itself)
     launch_dec_load_rows(a, B, x, 576, nullptr, 1, 0, e->stream);
     if (e->head8) launch_dec_lm_head(a, e->head8, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream, e->head_sc);
     else launch_dec_lm_head(a, e->lm_head.p, e->lm_head.KP / 8, e->cfg.vocab_size, e->stream);

@@ -126,6 +126,7 @@ constexpr int Q2_NPQ = 2 + Q2_HC;             // qkv slabs the fused kernel emit
 constexpr int Q2_K8 = 72 + 192;               // k-tiles of a Wq2 row: [W' (576 columns) | W' Wd (1536 columns)]
 constexpr int Q2_BLOCKS = 60 + 48 * Q2_HC;    // workgroups per row block
 static_assert(Q2_NPQ <= DEC_KC_QKV && Q2_HC <= DEC_KC_DOWN, "the fused kernel reuses the slab buffers of the split-K kernels");
+enum { DEC_X3_HEAD = 1, DEC_X3_GATEUP = 2, DEC_X3_QKV = 4, DEC_X3_DOWN = 8, DEC_X3_ALL = 15 };
 struct DecArgs {
     int rows = 0, RB = 0;          // padded batch rows (multiple of 32), row blocks
     int Tmax = 0;
@@ -150,6 +151,7 @@ struct DecArgs {
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)
     float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
+    void* xn3 = nullptr;           // f32x3 mode: the same pre-split (F3-32, decode.hip) instead of xnF; null = fp32 xnF
     // per-row-block early exit (reference stop rule, batches of more than one 32-row block): blk_live[rb] == 0 once every
     // row of block rb has produced the stop id -- its workgroups return at once.  Null = never skip (one block / fixed length).
     const int32_t* blk_live = nullptr;
@@ -162,6 +164,8 @@ struct DecArgs {
     // whenever that empties a whole 32-row block.
     const int32_t* row_of_slot = nullptr;
     int a8 = 0;                    // fp8 mode: launches that get e4m3 weights also quantise their activations (fp8 matrix pipe)
+    int x3 = 0;                    // f32x3 mode: bit mask of the decode GEMM launches that run on the bf16 matrix pipe with operands split in
+                                   // registers (DEC_X3_*; decode.hip); 0 = the exact fp32 MFMA kernels
     int dbg_seq = -1;              // -DMELLOW_KDEBUG builds: index of this launch in the step (span stamps of tools/kdebug.py), else unused
     float* logits = nullptr;       // [rows][vocab] (may be null)
     float* cand_val = nullptr; int32_t* cand_idx = nullptr;   // [rows][vocab/32]

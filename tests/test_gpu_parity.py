@@ -795,6 +795,12 @@ def test_wrapper_end_to_end_from_wav_files(synth_sd, tmp_path):
     m.model.close()
 
 
+# (row, first differing step) of the 32 x 300 run against the reference's own run (b32long.npz), per precision mode, as measured
+# on MI355X this round; every entry is one of the reference's nine near-ties (gap < 6e-3).  Token-exact decisions: 9600 minus
+# the tails of these rows.
+_B32LONG_DEPARTURES = {"f32": {(10, 153)}, "f32x3": {(10, 153)}}
+
+
 def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
     """BASELINE configs[2] at its exact per-rank shape: 32 examples, top_p=0.8, temperature=1.0, max_len=300 (context 389..689).
     The 32 x 300 tokens are held to the REFERENCE's own 300-step run of the 32 examples (b32long.npz: the imported reference's
@@ -809,33 +815,34 @@ def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
     b32 = np.load(os.path.join(golden_dir, "b32.npz"))
     assert np.array_equal(t300[:, : b32["tokens"].shape[1]], b32["tokens"])
     long_path = os.path.join(golden_dir, "b32long.npz")
-    if os.path.exists(long_path):
-        gl = np.load(long_path)
-        # 9600 greedy decisions; the reference's own top-2 logit gap is below the 3e-3 logit tolerance at a handful of them (the
-        # smallest: 8e-5 at (row 10, step 153), 2e-4 at (row 19, step 243)), where an fp32 implementation that differs from ATen's
-        # summation order may legitimately take the other token -- and then continues on another sequence.  So: every row must equal
-        # the reference up to its first such near-tie at least, a row may only leave the reference AT a near-tie (gap < 2 x 3e-3),
-        # and at most three rows may leave it at all.
-        left = []
-        for r in range(32):
-            d = np.flatnonzero(t300[r] != gl["tokens"][r])
-            if d.size:
-                st = int(d[0])
-                gap = float(gl["top2_gap"][st, r])
-                assert gap < 6e-3, f"row {r} leaves the reference's 300-step run at step {st} where its top-2 gap is {gap:.4f}"
-                left.append((r, st, gap))
-        assert len(left) <= 3, left
-        if left:
-            print("rows that took the other side of a reference near-tie (row, step, reference gap):", left)
-        # teacher-forced logits late in the run: prefill of [prefix | embed(reference tokens)] up to the kept step
-        pre = engine.prefix(a1[:8], a2[:8], ids[:8])
-        sd_embed = synth.make_state_dict(0)[spec.LM + "model.embed_tokens.weight"]
-        sub = torch.from_numpy(gl["sub_vocab"])
-        for k, st in enumerate(gl["keep_steps"].tolist()):
-            ext = torch.cat((pre.cpu(), sd_embed[torch.from_numpy(gl["tokens"][:8, :st]).long()]), 1)
-            lg = engine.lm_prefill(ext, reserve=2)
-            _close(lg[:, sub], gl["logits_sub"][k][:8], rel=0, atol=3e-3, name=f"rows 0..7 at step {st} (context {389 + st})")
-            assert lg.argmax(-1).cpu().tolist() == gl["tokens"][:8, st].tolist()
+    assert os.path.exists(long_path), "tests/golden/b32long.npz is part of the tree: configs[2] is pinned to it"
+    gl = np.load(long_path)
+    # 9600 greedy decisions; the reference's own top-2 logit gap is below twice the 3e-3 logit tolerance at NINE of them (counted
+    # and named in tests/test_oracle_golden.py::test_reference_near_ties_are_counted; the smallest: 8.4e-5 at (row 10, step 153),
+    # 2.1e-4 at (row 19, step 243)), where an fp32 implementation that differs from ATen's summation order may legitimately take
+    # the other token -- and then continues on another sequence.  Every row must equal the reference up to its first departure,
+    # a departure may only happen AT one of those nine decisions, and the departures of each precision mode are exactly the
+    # ones recorded here (an engine change that moves them has to be looked at and recorded).
+    near = {(int(r), int(s)) for s, r in np.argwhere(gl["top2_gap"] < 6e-3)}
+    left = []
+    for r in range(32):
+        d = np.flatnonzero(t300[r] != gl["tokens"][r])
+        if d.size:
+            left.append((r, int(d[0])))
+    mode = engine.precision
+    print(f"[{mode}] configs[2] per-rank run: {9600 - sum(300 - st for _, st in left)} of 9600 tokens equal the reference's; rows that "
+          f"left it (row, step, reference gap): {[(r, st, float(gl['top2_gap'][st, r])) for r, st in left]}")
+    assert set(left) <= near, f"[{mode}] a row leaves the reference's 300-step run away from a near-tie: {left}"
+    assert set(left) == _B32LONG_DEPARTURES[mode], f"[{mode}] departures from the reference's run moved: {left}"
+    # teacher-forced logits late in the run: prefill of [prefix | embed(reference tokens)] up to the kept step
+    pre = engine.prefix(a1[:8], a2[:8], ids[:8])
+    sd_embed = synth.make_state_dict(0)[spec.LM + "model.embed_tokens.weight"]
+    sub = torch.from_numpy(gl["sub_vocab"])
+    for k, st in enumerate(gl["keep_steps"].tolist()):
+        ext = torch.cat((pre.cpu(), sd_embed[torch.from_numpy(gl["tokens"][:8, :st]).long()]), 1)
+        lg = engine.lm_prefill(ext, reserve=2)
+        _close(lg[:, sub], gl["logits_sub"][k][:8], rel=0, atol=3e-3, name=f"rows 0..7 at step {st} (context {389 + st})")
+        assert lg.argmax(-1).cpu().tolist() == gl["tokens"][:8, st].tolist()
     t64, *_ = engine.generate(a1[:4], a2[:4], ids[:4], max_len=64, top_p=0.3, temperature=0.7, stop_id=0, ignore_stop=True)
     assert np.array_equal(t64, t300[:4, :64])
     # reference stop rule at this length: stop id := a token row 2 first produces late in the run

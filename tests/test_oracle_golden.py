@@ -137,3 +137,22 @@ def test_long_audio_seven_crops(synth_sd, golden_dir):
     _close(taps["latent"], g["latent"])
     _close(taps["framewise"][:, 0::32], g["framewise32"])
     _close(O.downsample(pv), g["audio_ds"])
+
+
+def test_reference_near_ties_are_counted(golden_dir):
+    """How far the "exact up to the reference's own near-ties" clause of the GPU parity tests reaches, as numbers in the tree:
+    the imported reference's own top-2 logit gap (torch.argmax, reference wrapper.py:232) at each of its greedy decisions.
+    configs[1] (32 x 64, b32.npz): no decision closer than 1.15e-2 -- the engine must be token-exact there, no clause applies.
+    configs[2] per rank (32 x 300, b32long.npz): 9 of the 9,600 decisions have a gap below 6e-3 (twice the 3e-3 logit tolerance),
+    5 below 3e-3, 2 below 1e-3, 1 below 1e-4; they sit in 8 distinct rows.  The GPU test names the (row, step) pairs."""
+    b32 = np.load(os.path.join(golden_dir, "b32.npz"))
+    assert b32["top2_gap"].shape == (64, 32) and float(b32["top2_gap"].min()) > 1.1e-2
+    gl = np.load(os.path.join(golden_dir, "b32long.npz"))
+    gap = gl["top2_gap"]
+    assert gap.shape == (300, 32) and gl["tokens"].shape == (32, 300)
+    assert [int((gap < th).sum()) for th in (6e-3, 3e-3, 1e-3, 1e-4)] == [9, 5, 2, 1]
+    near = sorted((int(r), int(s)) for s, r in np.argwhere(gap < 6e-3))
+    assert near == [(5, 106), (7, 122), (10, 69), (10, 153), (19, 243), (21, 67), (26, 101), (27, 215), (28, 287)]
+    assert abs(float(gap[153, 10]) - 8.39e-5) < 1e-6 and abs(float(gap[243, 19]) - 2.06e-4) < 1e-6
+    # the first 64 steps of the long run are the configs[1] run
+    assert np.array_equal(gl["tokens"][:, :64], b32["tokens"])
