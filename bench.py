@@ -363,7 +363,11 @@ def main():
     backend = os.environ.get("MELLOW_BENCH_BACKEND", "nccl")
     if "MELLOW_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["MELLOW_BENCH_DEVICE"])
-    if world > 1:
+    # MELLOW_BENCH_FORCE_DIST=1 (tests): run the distributed plumbing -- process-group init on "nccl" with device_id, the barrier,
+    # the MAX all-reduce of the time, the all-gather of the tokens -- also when the launcher gave this process WORLD_SIZE=1: on a
+    # 1-GPU box that is the only way to execute the exact calls the 8-GPU run makes on RCCL
+    use_dist = world > 1 or (os.environ.get("MELLOW_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -376,7 +380,7 @@ def main():
 
     from mellow_amd import synth, dist as mdist
     from mellow_amd.engine import Engine
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if use_dist else 0
     eng = Engine(device=dev, precision=args.precision)     # raises if libmellow_hip.so or the GPU is missing
     eng.load_state_dict(synth.make_state_dict(0))
     comm_dev = eng.tdev if backend == "nccl" else torch.device("cpu")      # where the collectives' buffers live
@@ -389,7 +393,7 @@ def main():
     def step():
         toks, lens, steps, ftm = eng.generate(a1d, a2d, idsd, max_len=L, top_p=0.8, temperature=1.0, stop_id=0,
                                               ignore_stop=True)
-        if world > 1:   # the path's single exchange: all-gather of the token ids over RCCL/xGMI
+        if use_dist:   # the path's single exchange: all-gather of the token ids over RCCL/xGMI
             mdist.gather_tokens(toks, lens, world * B, L, device=comm_dev)
         return ftm
 
@@ -397,16 +401,16 @@ def main():
     for _ in range(args.warmup):
         step()
     _progress("timed region")
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ftms = [step() for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -488,8 +492,10 @@ def main():
                                    f"{' (7 encoder crops per clip)' if n_crops > 1 else ''} + 16-token prompts, max_len={L}, "
                                    f"greedy, fixed-length (stop id ignored), seeded synthetic weights (real state_dict layout)",
                        "global_batch": n_gpus * B, "max_len": L, "parallelism": f"dp{n_gpus}", "preset": args.preset or "configs1"},
-            "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+            "ranks_seen": (dist.get_world_size() if use_dist else 1),
+            "dist_backend": (dist.get_backend() if use_dist else None),
             "env": mellow_env,
+            "prefill_parts": eng.prefill_parts(),      # measured by the engine: 2 = two half-batch chains on streams that overlap
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
             "roofline_gemm": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
@@ -547,7 +553,7 @@ def main():
             _progress("leg: cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(L)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -209,6 +209,14 @@ int         mellow_last_row_repacks(mellow_engine_t* e);
 /* 1 when this engine runs the STFT (A1, htsat.py:864) as a 1024-point FFT per frame instead of the DFT GEMM: f32x3 mode and a
  * checkpoint whose conv_real / conv_imag weights are window[n] * cos / sin(2 pi k n / 1024) to 1e-6 (checked at finalize). */
 int         mellow_stft_is_fft(mellow_engine_t* e);
+/* Number of independent parts the next f32x3 LM prefill of this engine runs as (2 by default: two half-batches on two HIP
+ * streams, so that one part's kernel tails are covered by the other's).  The engine OWNS this configuration: the first call
+ * (this function or the first prefill) creates the side stream(s) and MEASURES with a device-clock probe whether they really
+ * run beside the main stream -- HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
+ * otherwise when the runtime starts), and two streams that share a queue serialise.  A side stream that does not overlap is
+ * replaced (up to 8 attempts); if none does, the engine falls back to ONE chain and this function returns 1.  Results are
+ * bit-identical for every value; only the speed differs (the reference has no counterpart: wrapper.py:87-88 is its device model). */
+int         mellow_prefill_parts(mellow_engine_t* e);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

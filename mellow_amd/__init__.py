@@ -3,10 +3,12 @@
 `from mellow_amd import MellowWrapper` mirrors `from mellow import MellowWrapper` of the reference."""
 import os as _os
 
-# HIP maps streams onto a few hardware queues (4 by default).  An engine uses up to two streams for its split LM prefill and a
-# serving pool one main stream per context; with 4 queues two of them can land on ONE queue and serialise (right answers, no
-# overlap: measured as `pipelined` 543 -> 443 responses/s).  The variable is read when the HIP runtime initialises, i.e. at the
-# process's first GPU call -- a host that touches the GPU before importing this package should export it itself.
+# A CONVENIENCE, not a requirement: HIP maps streams onto a few hardware queues (4 by default).  The engine itself measures
+# whether the side stream of its split LM prefill runs beside its main stream and replaces it / falls back to one chain when
+# it does not (mellow_prefill_parts, include/mellow_hip.h), so a raw C-ABI consumer needs nothing from this file.  A serving
+# pool (serve.py) wants one queue per context on top of that; with 4 queues two contexts can land on ONE queue and serialise
+# (right answers, no overlap: measured as `pipelined` 543 -> 443 responses/s).  The variable is read when the HIP runtime
+# initialises, i.e. at the process's first GPU call -- a host that touches the GPU before importing this package should export it itself.
 if "GPU_MAX_HW_QUEUES" not in _os.environ:
     _os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import sys as _sys

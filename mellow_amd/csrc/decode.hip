@@ -164,6 +164,72 @@ __device__ __forceinline__ int64_t f32_idx(int rb, int K8, int m, int k) {
 }
 
 // ----------------------------------------------------------------------------------------------------
+// f32x3 mode (the engine's default): the decode GEMMs on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand value is
+// the EXACT sum of three bf16 pieces (split3, common.h: the same split as the prefill GEMMs of gemm_bf16x3.hip), formed here
+// IN REGISTERS right after the fp32 fragments have landed -- the weights stay 4 bytes per value in HBM, the activations stay
+// fp32 between launches -- and the six largest partial products run on v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD for
+// K = 16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same K), smallest first, fp32 accumulation.  No repacking:
+// a lane's float4 of k-tile t and of k-tile t + 1 are the eight k positions of its bf16 operand; A (weights, P-layout) and
+// B (activations, F32-layout) agree on which k a slot holds (lane half h of tile t: k = 8t + 4h + j), which is all the
+// contraction needs (the e4m3 form above pairs its tiles the same way).
+// Row blocks: one workgroup serves EVERY 32-row block of the batch with the weight fragments it split once (the fp32 kernels
+// above replicate the grid per row block and re-stream the weights).
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_pair(float4 a, float4 b, i32x4& p0, i32x4& p1, i32x4& p2) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    split8(v, p0, p1, p2);
+}
+#define MELLOW_BF16(W, X, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), ACC, 0, 0, 0)
+// six of the nine partial products, smallest first (pieces: 0 = leading, 2 = trailing; dropped: (1,2), (2,1), (2,2) < 2^-23 |w x|)
+__device__ __forceinline__ f32x16 mma6(f32x16 acc, const i32x4 (&w)[3], const i32x4 (&x)[3]) {
+    MELLOW_BF16(w[2], x[0], acc);
+    MELLOW_BF16(w[0], x[2], acc);
+    MELLOW_BF16(w[1], x[1], acc);
+    MELLOW_BF16(w[1], x[0], acc);
+    MELLOW_BF16(w[0], x[1], acc);
+    MELLOW_BF16(w[0], x[0], acc);
+    return acc;
+}
+
+// Pre-split activations ("F3" layouts): where ONE launch produces an activation that MANY workgroups of the next launch
+// multiply, the producer also stores it as bf16 triples in the consumer's fragment order, so that the split is paid once per
+// value instead of once per consuming workgroup (the lm_head has 1536 of them).  6 bytes per value instead of 4.
+//   F3-32 (B operand of v_mfma_f32_32x32x16_bf16; K8 = K / 8 tiles, pairs T = K / 16):
+//       16-byte slot ((rb * K/16 + T) * 3 + piece) * 64 + lane,  lane = m % 32 + 32 h;  element e of the slot:
+//       k = 16 T + 4 h + e (e < 4),  16 T + 8 + 4 h + (e - 4)  -- the lane's float4 of k-tile 2T and of k-tile 2T + 1 (F32-layout)
+//   F3-16 (B operand of v_mfma_f32_16x16x32_bf16; k16 tiles t, pairs T = K / 32, row halves mh):
+//       slot (((rb * K/32 + T) * 2 + mh) * 3 + piece) * 64 + lane,  lane = m % 16 + 16 q;  k = 32 T + 4 q + e (e < 4),
+//       32 T + 16 + 4 q + (e - 4)  -- the lane's float4 of k16-tile 2T and 2T + 1 (F16-layout)
+// A producer thread that owns four consecutive k of one row stores 8 bytes (4 bf16) per piece: element half eh of the slot.
+struct F3Quad { uint2 p[3]; };      // four consecutive k of one row as bf16 triples: p[piece] = 4 bf16
+__device__ __forceinline__ F3Quad f3_split4(float4 y) {
+    __bf16 h[4], m[4], l[4];
+    split3(y.x, h[0], m[0], l[0]); split3(y.y, h[1], m[1], l[1]); split3(y.z, h[2], m[2], l[2]); split3(y.w, h[3], m[3], l[3]);
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    F3Quad q;
+    q.p[0] = __builtin_bit_cast(uint2, bf16x4{h[0], h[1], h[2], h[3]});
+    q.p[1] = __builtin_bit_cast(uint2, bf16x4{m[0], m[1], m[2], m[3]});
+    q.p[2] = __builtin_bit_cast(uint2, bf16x4{l[0], l[1], l[2], l[3]});
+    return q;
+}
+__device__ __forceinline__ void f3_store(void* base, int64_t slot0, int eh, const F3Quad& q) {
+    uint2* p = reinterpret_cast<uint2*>(base) + slot0 * 2 + eh;
+    p[0] = q.p[0];
+    p[64 * 2] = q.p[1];
+    p[128 * 2] = q.p[2];
+}
+__device__ __forceinline__ void f3_store4(void* base, int64_t slot0, int eh, float4 y) { f3_store(base, slot0, eh, f3_split4(y)); }
+// slot of piece 0 for (row m of block rb, columns k .. k + 3, k % 4 == 0); *eh = element half
+__device__ __forceinline__ int64_t f3_32_slot(int rb, int KP, int m, int k, int* eh) {
+    *eh = (k >> 3) & 1;
+    return ((int64_t)rb * KP + (k >> 4)) * 3 * 64 + m + 32 * ((k >> 2) & 1);
+}
+__device__ __forceinline__ int64_t f3_16_slot(int rb, int KP, int m, int k, int* eh) {
+    *eh = (k >> 4) & 1;
+    return (((int64_t)rb * KP + (k >> 5)) * 2 + (m >> 4)) * 3 * 64 + (m & 15) + 16 * ((k >> 2) & 3);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // K1  qkv projection, split-K.  grid (30 n-tiles, DEC_KC_QKV, RB) = 240 workgroups, 3 waves x 3 k-tiles (+1 epilogue wave).
 //     X = baseF + sum_{s<KCD} dslabF[s]  (residual stream, un-normalised; norm weight folded into W)
 //     out: pq[kc][row][960] row-major slabs (consumer = attention, row-parallel)
@@ -758,6 +824,14 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         const float4 y = make_float4(xres.x + v[0], xres.y + v[1], xres.z + v[2], xres.w + v[3]);
         const int k = nt * 16 + enq * 4;
         st_out(reinterpret_cast<float4*>(a.xmidF) + f32_idx(rb, 72, mh * 16 + em, k), y);
+        if (a.xmid3_32) {                  // f32x3 layer kernels: x_mid pre-split for the q/k/v part (F3-32) and for gate/up (F3-16)
+            const F3Quad yq = f3_split4(y);
+            int eh;
+            const int64_t s32 = f3_32_slot(rb, 36, mh * 16 + em, k, &eh);
+            f3_store(a.xmid3_32, s32, eh, yq);
+            const int64_t s16 = f3_16_slot(rb, 18, mh * 16 + em, k, &eh);
+            f3_store(a.xmid3_16, s16, eh, yq);
+        } else
         st_out(reinterpret_cast<float4*>(a.xmidF16) + (((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq, y);
         float ss = f4ssq(y);
         ss += dpp_mov<0xB1>(ss);             // sum over the quad (the 4 column groups of one row)
@@ -873,63 +947,6 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
         }
     }
     kspan(a.dbg_seq, 1);
-}
-
-// ----------------------------------------------------------------------------------------------------
-// f32x3 mode (the engine's default): the decode GEMMs on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand value is
-// the EXACT sum of three bf16 pieces (split3, common.h: the same split as the prefill GEMMs of gemm_bf16x3.hip), formed here
-// IN REGISTERS right after the fp32 fragments have landed -- the weights stay 4 bytes per value in HBM, the activations stay
-// fp32 between launches -- and the six largest partial products run on v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD for
-// K = 16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same K), smallest first, fp32 accumulation.  No repacking:
-// a lane's float4 of k-tile t and of k-tile t + 1 are the eight k positions of its bf16 operand; A (weights, P-layout) and
-// B (activations, F32-layout) agree on which k a slot holds (lane half h of tile t: k = 8t + 4h + j), which is all the
-// contraction needs (the e4m3 form above pairs its tiles the same way).
-// Row blocks: one workgroup serves EVERY 32-row block of the batch with the weight fragments it split once (the fp32 kernels
-// above replicate the grid per row block and re-stream the weights).
-// ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split_pair(float4 a, float4 b, i32x4& p0, i32x4& p1, i32x4& p2) {
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    split8(v, p0, p1, p2);
-}
-#define MELLOW_BF16(W, X, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), ACC, 0, 0, 0)
-// six of the nine partial products, smallest first (pieces: 0 = leading, 2 = trailing; dropped: (1,2), (2,1), (2,2) < 2^-23 |w x|)
-__device__ __forceinline__ f32x16 mma6(f32x16 acc, const i32x4 (&w)[3], const i32x4 (&x)[3]) {
-    MELLOW_BF16(w[2], x[0], acc);
-    MELLOW_BF16(w[0], x[2], acc);
-    MELLOW_BF16(w[1], x[1], acc);
-    MELLOW_BF16(w[1], x[0], acc);
-    MELLOW_BF16(w[0], x[1], acc);
-    MELLOW_BF16(w[0], x[0], acc);
-    return acc;
-}
-
-// Pre-split activations ("F3" layouts): where ONE launch produces an activation that MANY workgroups of the next launch
-// multiply, the producer also stores it as bf16 triples in the consumer's fragment order, so that the split is paid once per
-// value instead of once per consuming workgroup (the lm_head has 1536 of them).  6 bytes per value instead of 4.
-//   F3-32 (B operand of v_mfma_f32_32x32x16_bf16; K8 = K / 8 tiles, pairs T = K / 16):
-//       16-byte slot ((rb * K/16 + T) * 3 + piece) * 64 + lane,  lane = m % 32 + 32 h;  element e of the slot:
-//       k = 16 T + 4 h + e (e < 4),  16 T + 8 + 4 h + (e - 4)  -- the lane's float4 of k-tile 2T and of k-tile 2T + 1 (F32-layout)
-//   F3-16 (B operand of v_mfma_f32_16x16x32_bf16; k16 tiles t, pairs T = K / 32, row halves mh):
-//       slot (((rb * K/32 + T) * 2 + mh) * 3 + piece) * 64 + lane,  lane = m % 16 + 16 q;  k = 32 T + 4 q + e (e < 4),
-//       32 T + 16 + 4 q + (e - 4)  -- the lane's float4 of k16-tile 2T and 2T + 1 (F16-layout)
-// A producer thread that owns four consecutive k of one row stores 8 bytes (4 bf16) per piece: element half eh of the slot.
-__device__ __forceinline__ void f3_store4(void* base, int64_t slot0, int eh, float4 y) {
-    __bf16 h[4], m[4], l[4];
-    split3(y.x, h[0], m[0], l[0]); split3(y.y, h[1], m[1], l[1]); split3(y.z, h[2], m[2], l[2]); split3(y.w, h[3], m[3], l[3]);
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    uint2* p = reinterpret_cast<uint2*>(base) + slot0 * 2 + eh;
-    p[0] = __builtin_bit_cast(uint2, bf16x4{h[0], h[1], h[2], h[3]});
-    p[64 * 2] = __builtin_bit_cast(uint2, bf16x4{m[0], m[1], m[2], m[3]});
-    p[128 * 2] = __builtin_bit_cast(uint2, bf16x4{l[0], l[1], l[2], l[3]});
-}
-// slot of piece 0 for (row m of block rb, columns k .. k + 3, k % 4 == 0); *eh = element half
-__device__ __forceinline__ int64_t f3_32_slot(int rb, int KP, int m, int k, int* eh) {
-    *eh = (k >> 3) & 1;
-    return ((int64_t)rb * KP + (k >> 4)) * 3 * 64 + m + 32 * ((k >> 2) & 1);
-}
-__device__ __forceinline__ int64_t f3_16_slot(int rb, int KP, int m, int k, int* eh) {
-    *eh = (k >> 4) & 1;
-    return (((int64_t)rb * KP + (k >> 5)) * 2 + (m >> 4)) * 3 * 64 + (m & 15) + 16 * ((k >> 2) & 3);
 }
 
 #ifndef MELLOW_LM3_WAVES
@@ -1175,6 +1192,251 @@ __global__ __launch_bounds__(H3_NW * 64) void dec_head3_kernel(const float* __re
             }
         }
         if (rb0 + G < RB_p) __syncthreads();          // the next pass refills stage 0
+    }
+    kspan(a.dbg_seq, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// f32x3 forms of the two big GEMM launches of a decode layer, for batches of MORE than one 32-row block (north_star's batch 64,
+// BASELINE configs[3] / [4]): the same workgroup -> weight-tile mapping, slab outputs and consumers as dec_qkv2_kernel /
+// dec_gateup16_kernel, but
+//   * ONE workgroup serves every row block: its weight fragments are loaded once and split to bf16 triples once (the fp32
+//     kernels replicate the grid per row block: weights re-read, fp32 MFMA time per block),
+//   * the activations arrive pre-split from their producer (F3 layouts above: o_proj writes x_mid, gate/up writes h), so a
+//     row block costs 3 x 16-byte loads and six bf16 MFMAs per k-pair and no VALU,
+//   * RBM row blocks are accumulated in registers per pass, one LDS reduction across the waves per pass.
+// ----------------------------------------------------------------------------------------------------
+#define MELLOW_BF16S(W, X, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), ACC, 0, 0, 0)
+__device__ __forceinline__ f32x4 mma6s(f32x4 acc, const i32x4 (&w)[3], const i32x4 (&x)[3]) {
+    MELLOW_BF16S(w[2], x[0], acc);
+    MELLOW_BF16S(w[0], x[2], acc);
+    MELLOW_BF16S(w[1], x[1], acc);
+    MELLOW_BF16S(w[1], x[0], acc);
+    MELLOW_BF16S(w[0], x[1], acc);
+    MELLOW_BF16S(w[0], x[0], acc);
+    return acc;
+}
+// One wave's share of a 32-row weight tile: NP k-pairs of W (fp32, P-layout, tiles k8_0 ..) against the same pairs of every
+// row block's F3-32 activations.  acc[g] += W . x[rb0 + g] for g < gn.
+template <int NP, int NPA>
+__device__ __forceinline__ void x3_load(i32x4 (&xq)[NPA][3], const i32x4* __restrict__ x3, int64_t off) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xq[p][c] = x3[off + (p * 3 + c) * 64];
+}
+// xq[0] holds the fragments of block rb0 on entry (requested by the caller together with the weights)
+template <int NP, int RBM, int NPA>
+__device__ __forceinline__ void x3_tile_job(const i32x4 (&wp)[NPA][3], i32x4 (&xq)[2][NPA][3], const i32x4* __restrict__ x3 /* (rb 0, pair T0, piece 0, lane) */,
+                                            int64_t rb_stride, int rb0, int gn, f32x16 (&acc)[RBM]) {
+#pragma unroll
+    for (int g = 0; g < RBM; ++g) {
+        if (g < gn) {
+            if (g + 1 < RBM && g + 1 < gn) x3_load<NP, NPA>(xq[(g + 1) & 1], x3, (int64_t)(rb0 + g + 1) * rb_stride);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[g] = mma6(acc[g], wp[p], xq[g & 1][p]);
+        }
+    }
+}
+#ifndef MELLOW_Q3_WAVES
+#define MELLOW_Q3_WAVES 6
+#endif
+constexpr int Q3W = MELLOW_Q3_WAVES;
+// K5+K1 (f32x3, any number of row blocks): see dec_qkv2_kernel for the algebra and the workgroup types.  xmid3 = x_mid in F3-32
+// (36 pairs per row block), h3 = h in F3-32 (96 pairs).
+// One workgroup's job for either type (NP k-pairs per wave): weights + the first block's fragments requested together, weights
+// split once, RBM row blocks accumulated per pass, one LDS reduction per pass, slabs out.
+template <int NP, int RBM, bool BLK>
+__device__ __forceinline__ void q3_body(const float4* __restrict__ wp4, const i32x4* __restrict__ xsrc, int64_t rb_stride, int nt, int slab,
+                                        bool side, int RB_p, const DecArgs& a, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i32x4 wp[NP][3];
+    i32x4 xq[2][NP][3];
+    {
+        float4 w[2 * NP];
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) w[i] = ldg_nt(wp4 + i * 64);
+        x3_load<NP, NP>(xq[0], xsrc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+    }
+    for (int rb0 = 0; rb0 < RB_p; rb0 += RBM) {
+        const int gn = min(RBM, RB_p - rb0);
+        f32x16 acc[RBM];
+#pragma unroll
+        for (int g = 0; g < RBM; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        if (rb0) x3_load<NP, NP>(xq[0], xsrc, (int64_t)rb0 * rb_stride);
+        x3_tile_job<NP, RBM, NP>(wp, xq, xsrc, rb_stride, rb0, gn, acc);
+        if (rb0) __syncthreads();                 // the previous pass's epilogue has read `red`
+#pragma unroll
+        for (int g = 0; g < RBM; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * RBM + g) * 16 + r) * 64 + lane] = acc[g][r];
+        __syncthreads();
+        if (tid < 256) {
+            const int mm = tid & 31, hh = (tid >> 5) & 1, gq = tid >> 6;
+            const int n = nt * 32 + 8 * gq + 4 * hh;
+            for (int g = 0; g < gn; ++g) {
+                const int rb = rb0 + g;
+                if (BLK && a.blk_live[rb] == 0) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 4 * gq + j;
+                    float sacc = red[((0 * RBM + g) * 16 + q) * 64 + mm + 32 * hh];
+#pragma unroll
+                    for (int wv = 1; wv < Q3W; ++wv) sacc += red[((wv * RBM + g) * 16 + q) * 64 + mm + 32 * hh];      // fixed order
+                    v[j] = sacc;
+                }
+                const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (side) st_out(reinterpret_cast<float4*>(a.dslabF) + (int64_t)slab * a.slabF_stride4 + f32_idx(rb, 72, mm, n), o);
+                else st_out(reinterpret_cast<float4*>(a.pq + ((int64_t)slab * a.rows + rb * 32 + mm) * 960 + n), o);
+            }
+        }
+    }
+}
+template <bool BLK, int RBM>
+__global__ __launch_bounds__(Q3W * 64) void dec_qkv2x3_kernel(const float* __restrict__ Wx, const float* __restrict__ Wh,
+                                                              const float* __restrict__ Wd, const i32x4* __restrict__ xmid3,
+                                                              const i32x4* __restrict__ h3, int K8x, int K8h, int RB_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
+    extern __shared__ __attribute__((aligned(16))) float red_dyn[];        // [Q3W][RBM][16][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    constexpr int XP = 18 / Q3W, HP = (96 / Q2_HC) / Q3W;                    // k-pairs per wave
+    static_assert(XP * Q3W == 18 && HP * Q3W * Q2_HC == 96 && Q3W * 64 >= 256, "waves must divide the k-chunks into whole pairs; the epilogue is 256 threads wide");
+    if (b < 60) {              // x part (workgroup-uniform branch; each side is its own straight-line body)
+        const int nt = b % 30, slab = b / 30;
+        const int T0 = slab * 18 + wave * XP;
+        q3_body<XP, RBM, BLK>(reinterpret_cast<const float4*>(Wx) + ((int64_t)nt * K8x + 2 * T0) * 64 + lane, xmid3 + (int64_t)T0 * 3 * 64 + lane,
+                              (int64_t)36 * 3 * 64, nt, slab, false, RB_p, a, red_dyn);
+    } else {                   // h part
+        const int idx = b - 60, hc = idx / 48, nt = idx % 48;
+        const bool side = nt >= 30;
+        const int T0 = hc * (96 / Q2_HC) + wave * HP;
+        const float4* wp4 = side ? reinterpret_cast<const float4*>(Wd) + ((int64_t)(nt - 30) * 192 + 2 * T0) * 64 + lane
+                                 : reinterpret_cast<const float4*>(Wh) + ((int64_t)nt * K8h + 2 * T0) * 64 + lane;
+        q3_body<HP, RBM, BLK>(wp4, h3 + (int64_t)T0 * 3 * 64 + lane, (int64_t)96 * 3 * 64, side ? nt - 30 : nt, side ? hc : 2 + hc, side, RB_p, a, red_dyn);
+    }
+    kspan(a.dbg_seq, 1);
+}
+
+#ifndef MELLOW_GU3_WAVES
+#define MELLOW_GU3_WAVES 6
+#endif
+constexpr int GU3W = MELLOW_GU3_WAVES;
+// K4b (f32x3, any number of row blocks): see dec_gateup16_kernel.  x3 = x_mid in F3-16 (18 pairs x 2 row halves per block).
+// Writes h both as fp32 (guF: the last layer's fp32 down projection reads it) and pre-split (h3, F3-32 with 96 pairs).
+template <bool BLK, int RBM>
+__global__ __launch_bounds__(GU3W * 64) void dec_gateup3_kernel(const float* __restrict__ Wp16, const i32x4* __restrict__ x3,
+                                                                const float* __restrict__ ssq_in, int RB_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
+    extern __shared__ __attribute__((aligned(16))) float red_dyn[];        // [GU3W][RBM][8][64]
+    float* red = red_dyn;
+    constexpr int NP = 18 / GU3W;
+    static_assert(NP * GU3W == 18, "waves must divide the 18 k-pairs");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x;
+    const int T0 = wave * NP;
+    i32x4 wp[NP][3];
+    i32x4 xq[2][NP][2][3];
+    const i32x4* xsrc = x3 + (int64_t)T0 * 2 * 3 * 64 + lane;
+    constexpr int64_t RBS = (int64_t)18 * 2 * 3 * 64;          // slots per row block
+    {
+        const float4* wp4 = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * 36 + 2 * T0) * 64 + lane;
+        float4 w[2 * NP];
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) w[i] = ldg_nt(wp4 + i * 64);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) xq[0][p][c / 3][c % 3] = xsrc[(p * 6 + c) * 64];          // block 0, requested with the weights
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+    }
+    for (int rb0 = 0; rb0 < RB_p; rb0 += RBM) {
+        const int gn = min(RBM, RB_p - rb0);
+        // the epilogue's RMS statistic (36 partial sums per row, written by the o_proj): requested with the operands, not after
+        // the reduction barrier.  Epilogue thread e = tid (+ a second round when gn * 64 > the block): row block e / 64, row (e % 64) / 2
+        float4 s4[2][9];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GU3W * 64;
+            if (e < gn * 64 && (k == 0 || RBM * 64 > GU3W * 64)) {
+                const float4* sq = reinterpret_cast<const float4*>(ssq_in + ((int64_t)(rb0 + (e >> 6)) * 32 + ((e & 63) >> 1)) * 40);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) s4[k][j] = sq[j];
+            }
+        }
+        f32x4 acc0[RBM], acc1[RBM];
+        if (rb0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xq[0][p][c / 3][c % 3] = xsrc[(int64_t)rb0 * RBS + (p * 6 + c) * 64];
+        }
+#pragma unroll
+        for (int g = 0; g < RBM; ++g) {
+            acc0[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g < gn) {
+                if (g + 1 < RBM && g + 1 < gn) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) xq[(g + 1) & 1][p][c / 3][c % 3] = xsrc[(int64_t)(rb0 + g + 1) * RBS + (p * 6 + c) * 64];
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    acc0[g] = mma6s(acc0[g], wp[p], xq[g & 1][p][0]);
+                    acc1[g] = mma6s(acc1[g], wp[p], xq[g & 1][p][1]);
+                }
+            }
+        }
+        if (rb0) __syncthreads();
+#pragma unroll
+        for (int g = 0; g < RBM; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[((wave * RBM + g) * 8 + r) * 64 + lane] = acc0[g][r];
+                red[((wave * RBM + g) * 8 + 4 + r) * 64 + lane] = acc1[g][r];
+            }
+        __syncthreads();
+        // thread (g, m, q): as the epilogue of dec_gateup16_kernel, 64 threads per row block
+        static_assert(RBM * 64 <= 2 * GU3W * 64, "two epilogue rounds cover a pass");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * GU3W * 64;
+            if (e >= gn * 64 || (k == 1 && RBM * 64 <= GU3W * 64)) continue;
+            const int g = e >> 6, t = e & 63, rb = rb0 + g;
+            if (BLK && a.blk_live[rb] == 0) continue;
+            const int m = t >> 1, q = t & 1;
+            const int gl = (m & 15) + 16 * q, ul = gl + 32, rbase = (m >> 4) * 4;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) ss += (s4[k][j].x + s4[k][j].y) + (s4[k][j].z + s4[k][j].w);
+            const float r2 = 1.0f / sqrtf(ss / 576.0f + a.eps);
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gv = red[((0 * RBM + g) * 8 + rbase + r) * 64 + gl], uv = red[((0 * RBM + g) * 8 + rbase + r) * 64 + ul];
+#pragma unroll
+                for (int wv = 1; wv < GU3W; ++wv) {                       // fixed order
+                    gv += red[((wv * RBM + g) * 8 + rbase + r) * 64 + gl];
+                    uv += red[((wv * RBM + g) * 8 + rbase + r) * 64 + ul];
+                }
+                h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
+            }
+            const float4 hv = make_float4(h[0], h[1], h[2], h[3]);
+            st_out(reinterpret_cast<float4*>(a.guF) + ((int64_t)rb * 192 + nt) * 64 + m + 32 * q, hv);
+            int eh;
+            const int64_t sl = f3_32_slot(rb, 96, m, 8 * nt + 4 * q, &eh);
+            f3_store4(a.h3, sl, eh, hv);
+        }
     }
     kspan(a.dbg_seq, 1);
 }
@@ -1702,7 +1964,7 @@ __global__ __launch_bounds__(192) void dec_load_rows_kernel(const DecArgs a, con
 // ---- launchers -------------------------------------------------------------------------------------------
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel function AND per device (an engine per GPU, pools of host threads):
 // remembered per (function, device) under a lock; the attribute call itself is cheap but not free on a per-step path.
-static void set_max_lds(const void* fn, size_t bytes) {
+void set_max_dynamic_lds(const void* fn, size_t bytes) {
     if (bytes <= 64 * 1024) return;
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> done;
@@ -1797,6 +2059,33 @@ static void launch_dec_qkv2_any(const DecArgs& a, const float* Wx, int K8x, cons
 #undef MELLOW_Q2_MODES
 #undef MELLOW_Q2
 }
+void launch_dec_qkv2x3(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
+    const float* Wh = Wq2 + (size_t)72 * 64 * 4;
+    const i32x4 *x3 = reinterpret_cast<const i32x4*>(a.xmid3_32), *h3 = reinterpret_cast<const i32x4*>(a.h3);
+#define MELLOW_Q3(BLKV, RBMV)                                                                                        \
+    do {                                                                                                             \
+        const size_t lds = (size_t)Q3W * RBMV * 16 * 64 * 4;                                                         \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_qkv2x3_kernel<BLKV, RBMV>), lds);                             \
+        hipLaunchKernelGGL((dec_qkv2x3_kernel<BLKV, RBMV>), dim3(Q2_BLOCKS), dim3(Q3W * 64), lds, s, Wq2, Wh, Wd, x3, h3, Q2_K8, Q2_K8, a.RB, a); \
+    } while (0)
+    if (a.RB <= 1) { if (a.blk_live) MELLOW_Q3(true, 1); else MELLOW_Q3(false, 1); }
+    else if (a.RB == 2) { if (a.blk_live) MELLOW_Q3(true, 2); else MELLOW_Q3(false, 2); }
+    else { if (a.blk_live) MELLOW_Q3(true, 4); else MELLOW_Q3(false, 4); }
+#undef MELLOW_Q3
+}
+void launch_dec_gateup3(const DecArgs& a, const float* Wp16, hipStream_t s) {
+    const i32x4* x3 = reinterpret_cast<const i32x4*>(a.xmid3_16);
+#define MELLOW_G3(BLKV, RBMV)                                                                                        \
+    do {                                                                                                             \
+        const size_t lds = (size_t)GU3W * RBMV * 8 * 64 * 4;                                                         \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_gateup3_kernel<BLKV, RBMV>), lds);                            \
+        hipLaunchKernelGGL((dec_gateup3_kernel<BLKV, RBMV>), dim3(192), dim3(GU3W * 64), lds, s, Wp16, x3, (const float*)a.ssq, a.RB, a); \
+    } while (0)
+    if (a.RB <= 1) { if (a.blk_live) MELLOW_G3(true, 1); else MELLOW_G3(false, 1); }
+    else if (a.RB == 2) { if (a.blk_live) MELLOW_G3(true, 2); else MELLOW_G3(false, 2); }
+    else { if (a.blk_live) MELLOW_G3(true, 4); else MELLOW_G3(false, 4); }
+#undef MELLOW_G3
+}
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
     launch_dec_qkv2_any(a, Wq2, Q2_K8, Wq2 + (size_t)72 * 64 * 4, Q2_K8, Wd, nullptr, nullptr, nullptr, s);
 }
@@ -1871,9 +2160,9 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
 #define MELLOW_H3(GV, DV)                                                                                                 \
         do {                                                                                                              \
             const size_t lds = (size_t)2 * GV * H3_CP * 3 * 64 * 16;                                                      \
-            if (a.blk_live) { set_max_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, true>), lds);           \
+            if (a.blk_live) { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, true>), lds);           \
                               hipLaunchKernelGGL((dec_head3_kernel<GV, DV, true>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
-            else { set_max_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
+            else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
                    hipLaunchKernelGGL((dec_head3_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
         } while (0)
         if (a.RB == 1) MELLOW_H3(1, MELLOW_H3_D1); else if (a.RB == 2) MELLOW_H3(2, MELLOW_H3_D2); else MELLOW_H3(4, MELLOW_H3_D4);

@@ -300,13 +300,9 @@ __global__ __launch_bounds__(256) void layernorm_apb_kernel(const float* __restr
 void launch_layernorm_apb(const float* in, void* out_apb, int M, int C, const float* w, const float* b, const int32_t* row_map,
                           int ntok, hipStream_t s) {
     const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 98.8 KB at C = 768
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_apb_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<1>), 100 * 1024);       // per (function, device)
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<2>), 100 * 1024);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<3>), 100 * 1024);
     const dim3 grid((M + 31) / 32), block(256);
     i32x4* o = reinterpret_cast<i32x4*>(out_apb);
     if (C <= 256) hipLaunchKernelGGL((layernorm_apb_kernel<1>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
@@ -407,11 +403,7 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
 }
 void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s) {
     const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 74 KB at C = 576: two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rmsnorm_apb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&rmsnorm_apb_kernel), 96 * 1024);
     hipLaunchKernelGGL(rmsnorm_apb_kernel, dim3((M + 31) / 32), dim3(256), lds, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps);
 }
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s) {

@@ -332,6 +332,52 @@ int alloc_state_words(mellow_engine* e) {
     return 0;
 }
 
+// ---- the split prefill's side streams: created once, and MEASURED to run beside the main stream -----------------------------
+// One thread stamps the device-wide 100 MHz clock, spins for `ticks`, stamps again.
+__global__ void stream_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    out[0] = t0;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    out[1] = wall_clock64();
+}
+// true when a kernel enqueued on `b` right after one on `a` STARTS before the first has ended (different hardware queues)
+static int streams_overlap(mellow_engine* e, hipStream_t a, hipStream_t b, bool* yes) {
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), a));
+    HIPCHK(hipStreamSynchronize(a));
+    HIPCHK(hipStreamSynchronize(b));
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(1), 0, a, d, 20000ull);          // 200 us
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(1), 0, b, d + 2, 2000ull);       // 20 us
+    HIPCHK(hipStreamSynchronize(a));
+    HIPCHK(hipStreamSynchronize(b));
+    unsigned long long h[4];
+    HIPCHK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    *yes = h[2] < h[1];
+    return 0;
+}
+int ensure_prefill_streams(mellow_engine* e) {
+    if (e->streams_probed) return 0;
+    int nh = e->prefill_parts < 1 ? 1 : (e->prefill_parts > 4 ? 4 : e->prefill_parts);
+    for (int h = 1; h < nh; ++h) {
+        bool ok = false;
+        for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+            hipStream_t st = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            CHK(streams_overlap(e, e->stream, st, &ok));
+            for (int k = 1; k < h && ok; ++k) CHK(streams_overlap(e, e->stream2[k - 1], st, &ok));
+            if (ok) e->stream2[h - 1] = st; else hipStreamDestroy(st);
+        }
+        if (!ok) {                // this process's HIP runtime has no free hardware queue for us: one chain, and say so
+            for (int k = 1; k < h; ++k) { hipStreamDestroy(e->stream2[k - 1]); e->stream2[k - 1] = nullptr; }
+            e->prefill_parts = 1;
+            break;
+        }
+    }
+    e->streams_probed = true;
+    return 0;
+}
 extern "C" {
 
 int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_enqueued : -1; }
@@ -339,6 +385,14 @@ int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_en
 int mellow_last_row_repacks(mellow_engine_t* e) { return e ? e->last_compactions : -1; }
 
 int mellow_stft_is_fft(mellow_engine_t* e) { return e && e->fft_win ? 1 : 0; }
+
+int mellow_prefill_parts(mellow_engine_t* e) {
+    if (!e) return -1;
+    if (!e->f32x3_terms) return 1;             // only the f32x3 prefill splits
+    if (hipSetDevice(e->device) != hipSuccess) return -1;
+    if (ensure_prefill_streams(e) != 0) return -1;
+    return e->prefill_parts < 1 ? 1 : (e->prefill_parts > 4 ? 4 : e->prefill_parts);
+}
 
 int mellow_prof_enable(mellow_engine_t* e, int on) {
     if (!e) return fail("null engine");
@@ -405,6 +459,7 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     // (decode.hip); MELLOW_DECODE_X3=<mask of DEC_X3_*> is the developer A/B (0 = the exact fp32 MFMA decode kernels)
     const char* dx = getenv("MELLOW_DECODE_X3");
     e->dec_x3 = mode == MELLOW_PRECISION_F32X3 ? (dx ? atoi(dx) & DEC_X3_ALL : DEC_X3_ALL) : 0;
+    if (const char* mr = getenv("MELLOW_DECODE_X3_MIN_RB")) e->dec_x3_min_rb = atoi(mr) < 1 ? 1 : atoi(mr);
     return 0;
 }
 
@@ -419,7 +474,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
     c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb; c->enc_apb_stages = parent->enc_apb_stages; c->sk_max = parent->sk_max;
-    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3;
+    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3; c->dec_x3_min_rb = parent->dec_x3_min_rb;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;
     c->bn_alpha = parent->bn_alpha; c->bn_beta = parent->bn_beta;

@@ -113,6 +113,7 @@ struct mellow_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     int prefill_parts = 2;                      // parts of the split LM prefill (MELLOW_PREFILL_SPLIT, read when the engine is created)
+    bool streams_probed = false;                // the side streams exist and were measured to overlap the main one (ensure_prefill_streams)
     hipStream_t stream2[3] = {nullptr, nullptr, nullptr};      // further streams of the split LM prefill (run_prefill)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
@@ -188,6 +189,7 @@ struct mellow_engine {
     bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (off: MELLOW_FP8_DECODE_ACT=0)
     bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (off: MELLOW_FP8_PREFILL=0, a test isolating the decode weights)
     float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
+    int dec_x3_min_rb = 2;                       // ... and the fewest 32-row blocks at which the layer GEMM launches take their f32x3 forms (MELLOW_DECODE_X3_MIN_RB)
     int dec_x3 = 0;                              // f32x3 mode: DEC_X3_* mask of the decode GEMM launches on the bf16 pipe (MELLOW_DECODE_X3=mask, developer A/B)
     int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
     // f32x3 LM prefill without RMSNorm launches: the o_proj / down GEMMs write their output pre-split + its sum of squares,
@@ -276,6 +278,7 @@ int run_lm_head(mellow_engine* e, int B, int pending_kcd, const RecordArgs* rec)
 int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_positions = false);
 int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, bool inc_pos);
 int enqueue_decode_layers(mellow_engine* e, int B, const RecordArgs* rec);
+int ensure_prefill_streams(mellow_engine* e);      // creates + probes the split prefill's side streams; may lower e->prefill_parts to 1
 int encode_pair_to_prefix(mellow_engine* e, const float* a1, const float* a2, int64_t n_samples, const int32_t* ids, int B, float* prefix_out);
 void clear_bad_id(mellow_engine* e);
 int check_bad_id(mellow_engine* e);

@@ -44,6 +44,10 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         const size_t o_pq = take((size_t)DEC_KC_QKV * Bp * 960);
         const size_t o_att = take((size_t)DEC_TS * n_x), o_aml = take((size_t)DEC_TS * 9 * Bp * 2);
         const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 256), o_xmidF16 = take(n_x);
+        // f32x3 layer kernels: 6-byte pre-split images of x_mid (two fragment orders) and of h
+        const bool x3l = (e->dec_x3 & DEC_X3_GATEUP) && (e->dec_x3 & DEC_X3_QKV) && (int)RB >= e->dec_x3_min_rb && !e->fp8_decode &&
+                         e->layers.size() > 1 && e->layers[1].qkv2 != nullptr;
+        const size_t o_x3a = take(x3l ? n_x * 3 / 2 : 0), o_x3b = take(x3l ? n_x * 3 / 2 : 0), o_h3 = take(x3l ? RB * 192 * 256 * 3 / 2 : 0);
         const bool fresh = e->dec.cap < off;
         CHK(ensure(e, e->dec, off));
         CHK(ensure(e, e->dlogits, (size_t)Bp * V));
@@ -65,6 +69,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
         a.xn3 = (a.x3 & DEC_X3_HEAD) && !e->head8 ? (void*)(p + o_xnF) : nullptr;
+        a.xmid3_32 = x3l ? (void*)(p + o_x3a) : nullptr; a.xmid3_16 = x3l ? (void*)(p + o_x3b) : nullptr; a.h3 = x3l ? (void*)(p + o_h3) : nullptr;
         a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
         {
             // key split of the decode attention: balanced at the END of the reserved context, rounded down to whole
@@ -137,11 +142,10 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
     // streams, so the tails and the fill / drain of one part's kernels are covered by another's (every buffer is indexed by row
     // or by example, so a part is an offset; its pre-split operands get their own panel-aligned region).  Measured before it was
     // built with two forked contexts (tools/half_chain_probe.py).  MELLOW_PREFILL_SPLIT=n: n parts (1 = one chain, at most 4).
+    if (apb && !e->prof_on && e->prefill_parts > 1) CHK(ensure_prefill_streams(e));      // (may find that they would serialise: one chain)
     int nh = (apb && !e->prof_on) ? e->prefill_parts : 1;
     nh = nh < 1 ? 1 : (nh > 4 ? 4 : nh);
     if (nh > B) nh = B;
-    for (int h = 1; h < nh; ++h)
-        if (!e->stream2[h - 1]) HIPCHK(hipStreamCreateWithFlags(&e->stream2[h - 1], hipStreamNonBlocking));
     int hb0[4], hB[4];
     size_t prow[4];                                              // first row of each part's panel range
     hipStream_t hs[4] = {s, e->stream2[0], e->stream2[1], e->stream2[2]};
@@ -150,6 +154,22 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
         b0 += hB[h]; r += rup(hB[h] * T, 128);
     }
     const bool split = nh > 1;
+    // Once the side streams wait on ev_fork, EVERY exit from this function has to join them back into `s` (an early error return
+    // inside the layer loop would otherwise leave launches of the side streams running against buffers the caller's next call
+    // reuses or frees from `s`): the guard joins in its destructor unless the normal path already has.
+    struct Join {
+        mellow_engine* e; hipStream_t* hs; int nh; bool done;
+        int run() {
+            if (done) return 0;
+            done = true;
+            for (int h = 1; h < nh; ++h) {
+                HIPCHK(hipEventRecord(e->ev_join[h - 1], hs[h]));
+                HIPCHK(hipStreamWaitEvent(hs[0], e->ev_join[h - 1], 0));
+            }
+            return 0;
+        }
+        ~Join() { (void)run(); }
+    } join{e, hs, nh, !split};
     if (split) {
         HIPCHK(hipEventRecord(e->ev_fork, s));
         for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(hs[h], e->ev_fork, 0));
@@ -229,10 +249,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
         }
         if (last) break;
     }
-    for (int h = 1; h < nh; ++h) {
-        HIPCHK(hipEventRecord(e->ev_join[h - 1], hs[h]));
-        HIPCHK(hipStreamWaitEvent(s, e->ev_join[h - 1], 0));
-    }
+    CHK(join.run());
     if (all_positions) {        // x = the hidden states after all layers, every position (mellow_lm_forward_logits)
         HIPCHK(hipGetLastError());
         return 0;
@@ -280,7 +297,8 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
         // B = 256: 190.3 / 175.7, B = 512: 346.6 / 319.2 -- its composed operand is 1.7x the bytes of the two matrices it
         // replaces, and a larger batch is bound by bytes, not by launches); the e4m3 form was measured ahead at four row blocks
         // (round 3) and stays fused.  MELLOW_DECODE_FUSE_MAX_RB: developer override.
-        const bool fuse_rb = e->da.RB <= e->dec_fuse_max_rb;
+        const bool x3l = e->da.xmid3_32 != nullptr;       // f32x3 forms of gate/up and of the fused down + q/k/v launch (ensure_lm decides)
+        const bool fuse_rb = x3l || e->da.RB <= e->dec_fuse_max_rb;
         const bool fused_in = l > l_begin && ((w.qkv2 != nullptr && fuse_rb) || w.q2h8 != nullptr) && !same_w;
         DecArgs a = e->da;
         const int sq = e->dbg_seq0 >= 0 ? e->dbg_seq0 + 5 * (l - l_begin) : -1000;       // launch index inside the step (kdebug builds)
@@ -302,6 +320,7 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
         if (!(skip & 8))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
           if (w.gu8) launch_dec_gateup(da(3), w.gu8, s, w.gu_sc);
+          else if (x3l) launch_dec_gateup3(da(3), w.gu16, s);
           else launch_dec_gateup(da(3), w.gu16, s); }
         const LMLayerW* nx = (l + 1 < l_end && !same_w) ? &e->layers[l + 1] : nullptr;
         if (nx && ((nx->qkv2 && fuse_rb) || nx->q2h8)) {
@@ -309,6 +328,7 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
             if (!(skip & 16))
             { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * (2112.0 * 960.0 + 1536.0 * 576.0), (2112.0 * 960.0 + 1536.0 * 576.0) * (nx->q2h8 ? 1 : 4));
               if (nx->q2h8) launch_dec_qkv2_w8(da(4), nx->qkv8, nx->qkv_sc, nx->q2h8, nx->q2h_sc, w.dn8, w.dn_sc, s);
+              else if (x3l) launch_dec_qkv2x3(da(4), nx->qkv2, w.down.p, s);
               else launch_dec_qkv2(da(4), nx->qkv2, w.down.p, s); }
         } else if (!(skip & 16))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 1536.0, 576.0 * 1536.0 * 4);

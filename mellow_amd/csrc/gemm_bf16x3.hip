@@ -863,11 +863,7 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
     d.gn = (a.Nw + 127) / 128;
     d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
     const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                              // 72 KiB
-    static bool attr_q = false;
-    if (!attr_q) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_q = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), lds);
     hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
     if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
 }
@@ -885,12 +881,8 @@ static void launchw(const GemmArgs& a, hipStream_t s) {
     d.gm = 512 / d.gn < panels ? 512 / d.gn : panels;                      // workgroups per column tile (two per CU in all)
     d.ks = 1;
     const size_t lds = (size_t)(6 * (3 * 4 * 64)) * 16;                                 // 72 KiB
-    static bool attr_w = false;
-    if (!attr_w) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_w = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3w_kernel<false>), lds);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3w_kernel<true>), lds);
     if (a.act == ACT_GELU) hipLaunchKernelGGL((gemm_x3w_kernel<true>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
     else hipLaunchKernelGGL((gemm_x3w_kernel<false>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
 }
@@ -926,11 +918,7 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
     static const bool pipelined = !(getenv("MELLOW_X3_KERNEL") && getenv("MELLOW_X3_KERNEL")[0] == 'f');   // 'f' = the plain fused kernel
     if (pipelined && a.K % 16 == 0 && a.K >= 192) {      // shorter K: the 3-stage prologue costs more than it hides (K = 96: 77 vs 84 TF)
         const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                          // 72 KiB
-        static bool attr_p = false;
-        if (!attr_p) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_p = true;
-        }
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3p_kernel<EPI>), lds);
         d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
         hipLaunchKernelGGL((gemm_x3p_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
         if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
@@ -938,11 +926,7 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
     }
     if (ks16 == 2 && a.K % 32 == 0) {
         const size_t lds = (size_t)2 * (2 * 2 * 4 * 64 + 2 * 3 * 4 * 64) * 16;     // 80 KiB
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3f_kernel<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16x3f_kernel<EPI, 2>), lds);
         hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 2>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
     } else {
         const size_t lds = (size_t)2 * (2 * 4 * 64 + 3 * 4 * 64) * 16;             // 40 KiB

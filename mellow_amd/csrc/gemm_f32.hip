@@ -245,12 +245,7 @@ static void launch_cfg(const GemmArgs& a, hipStream_t s) {
     d.gm = (a.M + BM - 1) / BM;
     d.gn = (a.Nw + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI, BK>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI, BK>), lds);      // per (function, device)
     hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI, BK>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
 }
 

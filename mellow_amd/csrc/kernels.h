@@ -101,6 +101,10 @@ void launch_split_rows_apb(const float* A, int64_t lda, int M, int K, void* out,
 void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s);   // A split in registers (no pre-pass), K % 32 == 0, a_mode == A_PLAIN
 double gemm_flops(const GemmArgs& a);
 
+// Allow `bytes` of dynamic LDS (> 64 KiB) for a kernel function on the CURRENT device: remembered per (function, device) under a
+// lock (an engine per GPU, pools of host threads), return code reported on stderr.  No-op up to 64 KiB.
+void set_max_dynamic_lds(const void* fn, size_t bytes);
+
 // ---- decode step (decode.hip) --------------------------------------------------------------------------------
 // split factors are compile-time so that partial-sum ("slab") loads are fully unrolled and issued together
 constexpr int DEC_KC_QKV = 8;    // qkv: 72 k-tiles = 8 chunks x 3 waves x 3  (30 x 8 = 240 workgroups <= 256 CUs)
@@ -151,6 +155,9 @@ struct DecArgs {
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)
     float* xnF = nullptr;          // final-normed x, F32-layout (lm_head operand)
+    // f32x3 layer kernels (row blocks >= the engine's threshold): x_mid pre-split by the o_proj for the fused down + q/k/v launch
+    // (F3-32) and for gate/up (F3-16, replaces xmidF16), h pre-split by gate/up (F3-32, 96 pairs); null = the fp32 kernels
+    void *xmid3_32 = nullptr, *xmid3_16 = nullptr, *h3 = nullptr;
     void* xn3 = nullptr;           // f32x3 mode: the same pre-split (F3-32, decode.hip) instead of xnF; null = fp32 xnF
     // per-row-block early exit (reference stop rule, batches of more than one 32-row block): blk_live[rb] == 0 once every
     // row of block rb has produced the stop id -- its workgroups return at once.  Null = never skip (one block / fixed length).
@@ -179,6 +186,9 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
 // down projection of a layer + q/k/v projection of the next one: Wq2 = P-layout [30][Q2_K8] of [W'_{l+1} | W'_{l+1} Wd_l],
 // Wd = this layer's down weight in P-layout (K8p = 192)
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
+// f32x3 forms for any number of row blocks (operands a.xmid3_32 / a.h3 / a.xmid3_16 pre-split by the o_proj / gate-up launches)
+void launch_dec_qkv2x3(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
+void launch_dec_gateup3(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s);
 // the same launch on e4m3 weights: the unfused layer's q/k/v copy (72 k-tiles per n-tile), the composed W' Wd (192) and the
 // down copy, one scale per packed row each (launch_pack_dec_fp8)
 void launch_dec_qkv2_w8(const DecArgs& a, const float* Wx8, const float* sc_x, const float* Wh8, const float* sc_h,

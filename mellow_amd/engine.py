@@ -89,6 +89,7 @@ def load_library(path: Optional[str] = None):
         "mellow_last_steps_enqueued": (ci, [vp]),
         "mellow_last_row_repacks": (ci, [vp]),
         "mellow_stft_is_fft": (ci, [vp]),
+        "mellow_prefill_parts": (ci, [vp]),
         "mellow_engine_set_precision": (ci, [vp, ci]),
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
@@ -112,7 +113,7 @@ EXPORTED_SYMBOLS = (
     "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
-    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft",
+    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft", "mellow_prefill_parts",
     "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_debug_dec_head", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
 )
 
@@ -297,6 +298,11 @@ class Engine:
     def stft_is_fft(self) -> bool:
         """the STFT runs as an FFT (f32x3 mode, windowed-DFT conv weights) instead of the DFT GEMM"""
         return bool(self.lib.mellow_stft_is_fft(self.h))
+
+    def prefill_parts(self) -> int:
+        """parts the f32x3 LM prefill runs as (2 = two half-batches on two streams MEASURED to overlap; 1 = one chain, also the
+        fallback when this process's HIP runtime has no second hardware queue for the engine)"""
+        return int(self.lib.mellow_prefill_parts(self.h))
 
     def last_row_repacks(self) -> int:
         """how often the last generate() call packed the still-running rows into fewer 32-row blocks"""

@@ -170,3 +170,62 @@ def test_gather_runs_on_rccl_with_one_rank(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rccl ok" in r.stdout
+
+
+def test_bench_runs_end_to_end_on_rccl_with_one_rank():
+    """8-GPU readiness on a 1-GPU box: `bench.py` under the driver's launcher (`torch.distributed.run`) with the DEFAULT backend
+    ("nccl" = RCCL) and one rank -- process-group init with `device_id`, the barrier, the MAX all-reduce of the elapsed time and
+    the token all-gather of mellow_amd.dist all execute on RCCL with device buffers, and `ranks_seen` comes from
+    `dist.get_world_size()`.  (MELLOW_BENCH_FORCE_DIST=1: the launcher gives WORLD_SIZE=1, for which bench.py would otherwise
+    skip the group.)  The supplementary legs of the N = 1 line are switched off to keep the run short."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29751", HSA_ENABLE_IPC_MODE_LEGACY="0", MELLOW_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29751", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-alt-modes", "--no-b64", "--no-configs3", "--inflight", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["dist_backend"] == "nccl" and out["value"] > 0
+
+
+_LOAD_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch
+from mellow_amd import synth
+from mellow_amd.engine import Engine
+sd = synth.make_state_dict(0)
+t0 = time.perf_counter()
+eng = Engine(device=0)
+eng.load_state_dict(sd)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+free, total = torch.cuda.mem_get_info(0)
+a1, a2, ids = synth.make_batch(4)
+toks, *_ = eng.generate(a1, a2, ids, max_len=4, stop_id=0, ignore_stop=True)
+print("LOADED %.2f s  used_GiB %.2f  tokens %s" % (t1 - t0, (total - free) / 2**30, toks[0].tolist()), flush=True)
+"""
+
+
+def test_two_replicas_load_concurrently_and_fit(tmp_path):
+    """Startup of a data-parallel node, as far as one GPU can show it: two PROCESSES create an engine, load the 479-tensor
+    checkpoint (compose + pack kernels included) and finalize AT THE SAME TIME on one device, then both answer.  Checks that
+    replica + workspaces of N ranks fit (2 x < 8 GiB here against 288 GB per GPU on the node) and that concurrent loading
+    neither fails nor changes the tokens."""
+    script = tmp_path / "load_worker.py"
+    script.write_text(_LOAD_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ps = [subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+          for _ in range(2)]
+    outs = [p.communicate(timeout=1200) for p in ps]
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    lines = [next(l for l in so.splitlines() if l.startswith("LOADED")) for so, _ in outs]
+    toks = [l.split("tokens")[1] for l in lines]
+    assert toks[0] == toks[1], lines
+    for l in lines:
+        secs, gib = float(l.split()[1]), float(l.split()[4])
+        assert secs < 300 and gib < 16, l
+    print(lines)

@@ -69,6 +69,11 @@ def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope,
                             C.c_void_p(ids.data_ptr()), B, max_len, C.c_float(0.8), C.c_float(1.0), stop, 0,
                             C.c_void_p(out.data_ptr()), lens, C.byref(steps), C.byref(first_ms)))
     tokens = out[:, :steps.value].cpu().numpy()
+    # the engine owns its stream configuration: a raw C-ABI consumer gets the two-stream prefill in
+    # the f32x3 modes because the engine measured that its side stream overlaps the main one -- not because of an import
+    lib.mellow_prefill_parts.argtypes = [C.c_void_p]
+    parts = lib.mellow_prefill_parts(h)
+    assert parts == (1 if precision == 0 else 2), parts
     lib.mellow_engine_destroy.argtypes = [C.c_void_p]
     lib.mellow_engine_destroy(h)
     assert steps.value == max_len and first_ms.value > 0
