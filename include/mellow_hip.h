@@ -35,6 +35,14 @@ extern "C" {
 /* 2: out_tokens may hold -1 (never-computed steps), first_token_ms is host wall-clock time, a decode step needs a prefill of
  *    its own after mellow_generate / mellow_lm_forward_logits, the optional "mellow.rope_cos/sin" tensors, new symbols */
 #define MELLOW_ABI_VERSION 2
+/* Minor revisions (same struct layouts and symbol meanings: a version-2 caller keeps working; mellow_abi_minor() reports it):
+ *  1: the DEFAULT numeric mode of mellow_engine_create is MELLOW_PRECISION_F32X3 (round 4).  A caller that never calls
+ *     mellow_engine_set_precision gets fp32-accurate GEMMs whose LAST BITS depend on how many examples share the call
+ *     (split-K for small launches; from round 5 the decode step of a batch of more than 32 rows runs other kernels than one of
+ *     up to 32 rows): greedy tokens are asserted equal across those forms on the reference's fixtures, logits agree to 1e-3;
+ *     a caller that needs bit-identical, batch-size-independent GEMMs selects MELLOW_PRECISION_F32.
+ *  2: mellow_prefill_parts (round 5). */
+#define MELLOW_ABI_MINOR 2
 
 typedef struct mellow_engine mellow_engine_t;
 
@@ -217,6 +225,8 @@ int         mellow_stft_is_fft(mellow_engine_t* e);
  * replaced (up to 8 attempts); if none does, the engine falls back to ONE chain and this function returns 1.  Results are
  * bit-identical for every value; only the speed differs (the reference has no counterpart: wrapper.py:87-88 is its device model). */
 int         mellow_prefill_parts(mellow_engine_t* e);
+/* MELLOW_ABI_MINOR of the library */
+int         mellow_abi_minor(void);
 /* 1 = replay the decode step from a captured hipGraph (default), 0 = eager launches */
 int         mellow_set_graph(mellow_engine_t* e, int on);
 

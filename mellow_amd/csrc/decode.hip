@@ -194,13 +194,16 @@ __device__ __forceinline__ f32x16 mma6(f32x16 acc, const i32x4 (&w)[3], const i3
 // Pre-split activations ("F3" layouts): where ONE launch produces an activation that MANY workgroups of the next launch
 // multiply, the producer also stores it as bf16 triples in the consumer's fragment order, so that the split is paid once per
 // value instead of once per consuming workgroup (the lm_head has 1536 of them).  6 bytes per value instead of 4.
-//   F3-32 (B operand of v_mfma_f32_32x32x16_bf16; K8 = K / 8 tiles, pairs T = K / 16):
-//       16-byte slot ((rb * K/16 + T) * 3 + piece) * 64 + lane,  lane = m % 32 + 32 h;  element e of the slot:
-//       k = 16 T + 4 h + e (e < 4),  16 T + 8 + 4 h + (e - 4)  -- the lane's float4 of k-tile 2T and of k-tile 2T + 1 (F32-layout)
-//   F3-16 (B operand of v_mfma_f32_16x16x32_bf16; k16 tiles t, pairs T = K / 32, row halves mh):
-//       slot (((rb * K/32 + T) * 2 + mh) * 3 + piece) * 64 + lane,  lane = m % 16 + 16 q;  k = 32 T + 4 q + e (e < 4),
-//       32 T + 16 + 4 q + (e - 4)  -- the lane's float4 of k16-tile 2T and 2T + 1 (F16-layout)
-// A producer thread that owns four consecutive k of one row stores 8 bytes (4 bf16) per piece: element half eh of the slot.
+//   F3-32 (B operand of v_mfma_f32_32x32x16_bf16; pairs T = K / 16):
+//       16-byte slot ((rb * K/16 + T) * 3 + piece) * 64 + lane,  lane = m % 32 + 32 h;  element e of the slot: k = 16 T + 8 h + e
+//   F3-16 (B operand of v_mfma_f32_16x16x32_bf16; pairs T = K / 32, row halves mh):
+//       slot (((rb * K/32 + T) * 2 + mh) * 3 + piece) * 64 + lane,  lane = m % 16 + 16 q;  k = 32 T + 8 q + e
+// Eight CONSECUTIVE k per slot: a producer thread owns four consecutive k of one row, its neighbour (lane ^ 1) the other four
+// of the same slot, so the even thread of a pair collects both halves (one DPP step) and stores whole 16-byte slots -- no
+// workgroup ever writes half a slot (half-slot stores from two workgroups on different XCDs cost 0.9 us per launch).
+// The weight side agrees on the k order: a 32-row weight tile pair (P-layout: lane half h of tile t holds k = 8 t + 4 h + j) is
+// brought to k = 16 T + 8 h + e with one v_permlane32_swap per value (pair_natural); the 16-row gate/up tiles have their own
+// packed copy in that order (P16N, launch_pack_weight16n).
 struct F3Quad { uint2 p[3]; };      // four consecutive k of one row as bf16 triples: p[piece] = 4 bf16
 __device__ __forceinline__ F3Quad f3_split4(float4 y) {
     __bf16 h[4], m[4], l[4];
@@ -212,21 +215,38 @@ __device__ __forceinline__ F3Quad f3_split4(float4 y) {
     q.p[2] = __builtin_bit_cast(uint2, bf16x4{l[0], l[1], l[2], l[3]});
     return q;
 }
-__device__ __forceinline__ void f3_store(void* base, int64_t slot0, int eh, const F3Quad& q) {
-    uint2* p = reinterpret_cast<uint2*>(base) + slot0 * 2 + eh;
-    p[0] = q.p[0];
-    p[64 * 2] = q.p[1];
-    p[128 * 2] = q.p[2];
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+// the neighbour's quad (lane ^ 1).  Both threads of a pair must be active.
+__device__ __forceinline__ F3Quad f3_partner(const F3Quad& q) {
+    F3Quad o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o.p[c].x = dpp_xor1(q.p[c].x); o.p[c].y = dpp_xor1(q.p[c].y); }
+    return o;
 }
-__device__ __forceinline__ void f3_store4(void* base, int64_t slot0, int eh, float4 y) { f3_store(base, slot0, eh, f3_split4(y)); }
-// slot of piece 0 for (row m of block rb, columns k .. k + 3, k % 4 == 0); *eh = element half
-__device__ __forceinline__ int64_t f3_32_slot(int rb, int KP, int m, int k, int* eh) {
-    *eh = (k >> 3) & 1;
-    return ((int64_t)rb * KP + (k >> 4)) * 3 * 64 + m + 32 * ((k >> 2) & 1);
+// whole slot (columns k .. k + 7, k % 8 == 0): lo = the quad of k .. k + 3, hi = of k + 4 .. k + 7
+__device__ __forceinline__ void f3_store8(void* base, int64_t slot0, const F3Quad& lo, const F3Quad& hi) {
+    uint4* p = reinterpret_cast<uint4*>(base) + slot0;
+    p[0] = make_uint4(lo.p[0].x, lo.p[0].y, hi.p[0].x, hi.p[0].y);
+    p[64] = make_uint4(lo.p[1].x, lo.p[1].y, hi.p[1].x, hi.p[1].y);
+    p[128] = make_uint4(lo.p[2].x, lo.p[2].y, hi.p[2].x, hi.p[2].y);
 }
-__device__ __forceinline__ int64_t f3_16_slot(int rb, int KP, int m, int k, int* eh) {
-    *eh = (k >> 4) & 1;
-    return (((int64_t)rb * KP + (k >> 5)) * 2 + (m >> 4)) * 3 * 64 + (m & 15) + 16 * ((k >> 2) & 3);
+// slot of piece 0 for (row m of block rb, columns k .. k + 7, k % 8 == 0)
+__device__ __forceinline__ int64_t f3_32_slot(int rb, int KP, int m, int k) {
+    return ((int64_t)rb * KP + (k >> 4)) * 3 * 64 + m + 32 * ((k >> 3) & 1);
+}
+__device__ __forceinline__ int64_t f3_16_slot(int rb, int KP, int m, int k) {
+    return (((int64_t)rb * KP + (k >> 5)) * 2 + (m >> 4)) * 3 * 64 + (m & 15) + 16 * ((k >> 3) & 3);
+}
+// weight fragments of a tile pair (a = tile 2T, b = tile 2T + 1, P-layout) -> the slot order above: lane half 0 gets tile 2T's
+// eight k, lane half 1 tile 2T + 1's
+__device__ __forceinline__ void pair_natural(float4& a, float4& b) {
+    float* pa = &a.x; float* pb = &b.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(pa[j]), __float_as_uint(pb[j]), false, false);
+        pa[j] = __uint_as_float(r[0]);
+        pb[j] = __uint_as_float(r[1]);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -368,6 +388,24 @@ constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chun
 #endif
 constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key groups requested before the prologue
 
+// KV16 (fp8 mode): the decode step reads and extends a bf16 SHADOW of the K/V pages (engine_lm.cpp: converted from the fp32
+// pages the prefill wrote, once per call): half the bytes of the step's largest stream.  The new key / value of the step itself
+// are used in fp32 (from LDS) and appended rounded to nearest even.  One 8-byte load per lane = 4 bf16 of one key.
+template <bool KV16>
+__device__ __forceinline__ float4 ld_kv(const float* page, int64_t elem) {
+    if constexpr (KV16) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(page) + elem));
+        return make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u));
+    } else {
+        return ldg_nt(reinterpret_cast<const float4*>(page + elem));
+    }
+}
+template <bool KV16>
+__device__ __forceinline__ void st_kv(float* page, int64_t elem, float v) {
+    if constexpr (KV16) reinterpret_cast<__bf16*>(page)[elem] = static_cast<__bf16>(v);
+    else page[elem] = v;
+}
 // FUSED: the producer was dec_qkv2_kernel (the previous layer's down projection and this layer's q/k/v in one launch): the
 // projected values arrive as Q2_NPQ slabs, and x_new = x_mid + sum of the Q2_HC down slabs is formed HERE (the 144 float4 of the
 // row, by every workgroup of the row: its sum of squares is the RMS statistic; the (kv head 0, split 0) workgroup also writes the
@@ -375,7 +413,7 @@ constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key group
 // ONE: the launch has a single 32-row block (192 workgroups: one per CU, registers are free) -> the chunk loop in its plain form
 //      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
 //      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
-template <bool BLK, bool FUSED, bool ONE>
+template <bool BLK, bool FUSED, bool ONE, bool KV16>
 __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
                                                                   const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
                                                                   const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
@@ -401,8 +439,9 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tmax = Tmax_p;
-    float* kpage = k_cache + ((int64_t)row * 3 + g) * Tmax * 64;
-    float* vpage = v_cache + ((int64_t)row * 3 + g) * Tmax * 64;
+    // (KV16: the same element offsets into pages of 2-byte elements: half the float offset)
+    float* kpage = k_cache + (((int64_t)row * 3 + g) * Tmax * 64 >> (KV16 ? 1 : 0));
+    float* vpage = v_cache + (((int64_t)row * 3 + g) * Tmax * 64 >> (KV16 ? 1 : 0));
     const int sub = lane >> 4, quad = lane & 15;   // lane -> (key sub, dim quad): a wave instruction = 4 keys x 64 dims
 
     // ===== ONE round trip, every load independent and straight-line: position word, RMS partials, qkv slabs,
@@ -458,8 +497,8 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
             k4[u] = make_float4(0.01f * tc, 0.02f, 0.03f, 0.04f);
             v4[u] = make_float4(0.01f, 0.02f * tc, 0.03f, 0.04f);
         } else {
-            k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));
-            v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));
+            k4[u] = ld_kv<KV16>(kpage, (int64_t)tc * 64 + quad * 4);
+            v4[u] = ld_kv<KV16>(vpage, (int64_t)tc * 64 + quad * 4);
         }
     };
 #pragma unroll
@@ -508,12 +547,12 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
             qs[hsel * 64 + i + 32] = o2 * 0.125f;
         } else {
             knew[i] = o1; knew[i + 32] = o2;
-            if (sp == 0) { kpage[(int64_t)pos * 64 + i] = o1; kpage[(int64_t)pos * 64 + i + 32] = o2; }
+            if (sp == 0) { st_kv<KV16>(kpage, (int64_t)pos * 64 + i, o1); st_kv<KV16>(kpage, (int64_t)pos * 64 + i + 32, o2); }
         }
     } else if (tid < 192) {
         const float x1 = xs[256 + tid - 128] * rs2;
         vnew[tid - 128] = x1;
-        if (sp == 0) vpage[(int64_t)pos * 64 + (tid - 128)] = x1;
+        if (sp == 0) st_kv<KV16>(vpage, (int64_t)pos * 64 + (tid - 128), x1);
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -585,8 +624,8 @@ _Pragma("unroll")                                                               
         _Pragma("unroll") for (int u = 0; u < DA_G; ++u) {                                                               \
             const int gi = (g0) + u * DA_WAVES;                                                                          \
             const int tc = min(gi * 4 + sub, Tmax - 1);                                                                  \
-            k4[u] = ldg_nt(reinterpret_cast<const float4*>(kpage + (int64_t)tc * 64 + quad * 4));                        \
-            v4[u] = ldg_nt(reinterpret_cast<const float4*>(vpage + (int64_t)tc * 64 + quad * 4));                        \
+            k4[u] = ld_kv<KV16>(kpage, (int64_t)tc * 64 + quad * 4);                                                    \
+            v4[u] = ld_kv<KV16>(vpage, (int64_t)tc * 64 + quad * 4);                                                    \
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
@@ -825,12 +864,11 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         const int k = nt * 16 + enq * 4;
         st_out(reinterpret_cast<float4*>(a.xmidF) + f32_idx(rb, 72, mh * 16 + em, k), y);
         if (a.xmid3_32) {                  // f32x3 layer kernels: x_mid pre-split for the q/k/v part (F3-32) and for gate/up (F3-16)
-            const F3Quad yq = f3_split4(y);
-            int eh;
-            const int64_t s32 = f3_32_slot(rb, 36, mh * 16 + em, k, &eh);
-            f3_store(a.xmid3_32, s32, eh, yq);
-            const int64_t s16 = f3_16_slot(rb, 18, mh * 16 + em, k, &eh);
-            f3_store(a.xmid3_16, s16, eh, yq);
+            const F3Quad yq = f3_split4(y), yo = f3_partner(yq);      // threads (enq, enq ^ 1) hold the halves of one slot
+            if (!(enq & 1)) {
+                f3_store8(a.xmid3_32, f3_32_slot(rb, 36, mh * 16 + em, k), yq, yo);
+                f3_store8(a.xmid3_16, f3_16_slot(rb, 18, mh * 16 + em, k), yq, yo);
+            }
         } else
         st_out(reinterpret_cast<float4*>(a.xmidF16) + (((int64_t)rb * 36 + nt) * 2 + mh) * 64 + em + 16 * enq, y);
         float ss = f4ssq(y);
@@ -954,8 +992,8 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
 #endif
 constexpr int LM3_WAVES = MELLOW_LM3_WAVES;
 // K4x  lm_head, f32x3 form.  grid (n-tiles), LM3_WAVES waves x (72 / LM3_WAVES) k-tiles; loops over the row blocks.
-// XPRE: the activations arrive pre-split (F3-32, written by the final norm); otherwise they are split here (taps on caller rows)
-template <bool BLK, bool XPRE>
+// (taps on caller-supplied rows; generation runs dec_head3_kernel below on activations the final norm pre-split)
+template <bool BLK>
 __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
                                                                     int N, int RB_p, const DecArgs a) {
     kspan(a.dbg_seq, 0);
@@ -966,20 +1004,14 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
     const int nt = blockIdx.x;
     const int k8_0 = wave * KPW;
     const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
-    float4 w[KPW], x[XPRE ? 1 : KPW];
+    float4 w[KPW], x[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) w[i] = ldg_nt(reinterpret_cast<const float4*>(Wp) + wslot + i * 64);
     int rb = 0;
     if (BLK) { while (rb < RB_p && a.blk_live[rb] == 0) ++rb; }          // first live block (workgroup-uniform)
     if (rb >= RB_p) return;
-    i32x4 xq[PP][3], xn[XPRE ? PP : 1][3];
-    const i32x4* X3 = reinterpret_cast<const i32x4*>(XF) + (int64_t)wave * PP * 3 * 64 + lane;      // XPRE: XF = the F3-32 image
-    if constexpr (XPRE) {
-#pragma unroll
-        for (int p = 0; p < PP; ++p)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) xq[p][c] = X3[((int64_t)rb * 36 * 3 + p * 3 + c) * 64];
-    } else {
+    i32x4 xq[PP][3];
+    {
         const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
@@ -989,23 +1021,15 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
 #pragma unroll
     for (int p = 0; p < PP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
     while (rb < RB_p) {
-        if constexpr (!XPRE) {
+        // (both operands are fp32 fragments of the same two k-tiles: lane half h holds k = 8 t + 4 h + j of either tile on both sides)
 #pragma unroll
-            for (int p = 0; p < PP; ++p) split_pair(x[2 * p], x[2 * p + 1], xq[p][0], xq[p][1], xq[p][2]);
-        }
+        for (int p = 0; p < PP; ++p) split_pair(x[2 * p], x[2 * p + 1], xq[p][0], xq[p][1], xq[p][2]);
         int nrb = rb + 1;
         if (BLK) { while (nrb < RB_p && a.blk_live[nrb] == 0) ++nrb; }
         if (nrb < RB_p) {                   // the next block's fragments travel while this one is multiplied
-            if constexpr (XPRE) {
+            const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)nrb * 72 + k8_0) * 64 + lane;
 #pragma unroll
-                for (int p = 0; p < PP; ++p)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) xn[p][c] = X3[((int64_t)nrb * 36 * 3 + p * 3 + c) * 64];
-            } else {
-                const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)nrb * 72 + k8_0) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
-            }
+            for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
         }
         f32x16 acc;
 #pragma unroll
@@ -1055,14 +1079,6 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
             a.cand_idx[o] = idx;
         }
         if (nrb < RB_p) __syncthreads();          // the next block's partial sums reuse `red`
-        if constexpr (XPRE) {
-            if (nrb < RB_p) {
-#pragma unroll
-                for (int p = 0; p < PP; ++p)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) xq[p][c] = xn[p][c];
-            }
-        }
         rb = nrb;
     }
     kspan(a.dbg_seq, 1);
@@ -1142,7 +1158,10 @@ __global__ __launch_bounds__(H3_NW * 64) void dec_head3_kernel(const float* __re
                 __builtin_amdgcn_sched_barrier(0);       // (keeps the next chunks' loads where they are: ahead of this chunk's work)
                 i32x4 wp[H3_CP][3];
 #pragma unroll
-                for (int p = 0; p < H3_CP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+                for (int p = 0; p < H3_CP; ++p) {
+                    pair_natural(w[2 * p], w[2 * p + 1]);
+                    split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+                }
                 const i32x4* st = xs + (c & 1) * STAGE + lane;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -1192,6 +1211,118 @@ __global__ __launch_bounds__(H3_NW * 64) void dec_head3_kernel(const float* __re
             }
         }
         if (rb0 + G < RB_p) __syncthreads();          // the next pass refills stage 0
+    }
+    kspan(a.dbg_seq, 1);
+}
+
+// K4z  the same streaming lm_head with the activations RESIDENT in LDS: the G row blocks' fragments of 36 / G k-pairs fill the
+//      108 KiB stage once per phase (G phases), and inside a phase the waves run without any barrier -- each streams its own
+//      n-tile's weights D chunks ahead and reads the fragments it needs from LDS.  (K4y refills a small stage every chunk: one
+//      barrier + one L2 round trip per chunk, 12 per row-block pass, which is what bounds it at one row block.)
+template <int G, int D, bool BLK>
+__global__ __launch_bounds__(H3_NW * 64) void dec_head3r_kernel(const float* __restrict__ Wp, const i32x4* __restrict__ X3, int K8p, int N,
+                                                                int RB_p, const DecArgs a) {
+    kspan(a.dbg_seq, 0);
+    extern __shared__ __attribute__((aligned(16))) i32x4 xs[];        // [G][PPH][3][64]
+    constexpr int PPH = 36 / G, NCH = PPH / H3_CP;                     // pairs / chunks per phase
+    constexpr int STAGE = G * PPH * 3 * 64;                            // = 36 * 192 slots = 108 KiB
+    static_assert(PPH * G == 36 && NCH * H3_CP == PPH && H3_NC % D == 0 && NCH % D == 0, "phases hold whole chunks");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * H3_NW + wave;
+    const float4* wbase = reinterpret_cast<const float4*>(Wp) + (int64_t)nt * K8p * 64 + lane;
+    for (int rb0 = 0; rb0 < RB_p; rb0 += G) {
+        const int gn = min(G, RB_p - rb0);
+        f32x16 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        float4 wn[D][2 * H3_CP];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + (d * 2 * H3_CP + i) * 64);
+        for (int ph = 0; ph < G; ++ph) {
+            if (ph || rb0) __syncthreads();               // every wave has read the previous phase's fragments
+            // fill: slot i = (g, pair pp of the phase, piece, lane) <- X3[((rb0 + g) * 36 + ph * PPH + pp) * 3 + piece][lane]
+            {
+                constexpr int FILL = (STAGE + H3_NW * 64 - 1) / (H3_NW * 64);      // all loads of a thread in flight together
+                i32x4 t[FILL];
+#pragma unroll
+                for (int j = 0; j < FILL; ++j) {
+                    const int i = tid + j * H3_NW * 64;
+                    if (i < STAGE) {
+                        const int g = i / (PPH * 3 * 64), rest = i % (PPH * 3 * 64);
+                        t[j] = X3[(((int64_t)(rb0 + (g < gn ? g : 0)) * 36 + ph * PPH) * 3) * 64 + rest];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FILL; ++j) {
+                    const int i = tid + j * H3_NW * 64;
+                    if (i < STAGE) xs[i] = t[j];
+                }
+            }
+            __syncthreads();
+            for (int c0 = 0; c0 < NCH; c0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int cc = c0 + d, c = ph * NCH + cc;      // chunk of the phase / of the whole K
+                    float4 w[2 * H3_CP];
+#pragma unroll
+                    for (int i = 0; i < 2 * H3_CP; ++i) w[i] = wn[d][i];
+                    if (c + D < H3_NC) {
+#pragma unroll
+                        for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + ((c + D) * 2 * H3_CP + i) * 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    i32x4 wp[H3_CP][3];
+#pragma unroll
+                    for (int p = 0; p < H3_CP; ++p) {
+                        pair_natural(w[2 * p], w[2 * p + 1]);
+                        split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+                    }
+                    const i32x4* st = xs + (cc * H3_CP) * 3 * 64 + lane;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (g < gn) {
+#pragma unroll
+                            for (int p = 0; p < H3_CP; ++p) {
+                                const i32x4 xq[3] = {st[((g * PPH + p) * 3 + 0) * 64], st[((g * PPH + p) * 3 + 1) * 64], st[((g * PPH + p) * 3 + 2) * 64]};
+                                acc[g] = mma6(acc[g], wp[p], xq);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g < gn && !(BLK && a.blk_live[rb0 + g] == 0)) {
+                const int64_t row = (int64_t)(rb0 + g) * 32 + m;
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nt * 32 + 8 * q + 4 * h;
+                    if (a.logits) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (arg_better(acc[g][4 * q + j], n + j, bv, bi)) { bv = acc[g][4 * q + j]; bi = n + j; }
+                }
+                auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+                auto ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+                const float ov = __uint_as_float(h ? rv[0] : rv[1]);
+                const int oi = (int)(h ? ri[0] : ri[1]);
+                if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                if (h == 0) {
+                    const int64_t o = row * (N >> 5) + nt;
+                    a.cand_val[o] = bv;
+                    a.cand_idx[o] = bi;
+                }
+            }
+        }
     }
     kspan(a.dbg_seq, 1);
 }
@@ -1252,14 +1383,19 @@ __device__ __forceinline__ void q3_body(const float4* __restrict__ wp4, const i3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     i32x4 wp[NP][3];
     i32x4 xq[2][NP][3];
+    constexpr bool ALL = RBM <= 2;            // a pass's fragments fit the registers: request all of them at once (no dependent second round trip)
     {
         float4 w[2 * NP];
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) w[i] = ldg_nt(wp4 + i * 64);
         x3_load<NP, NP>(xq[0], xsrc, 0);
+        if (ALL && RBM == 2 && RB_p > 1) x3_load<NP, NP>(xq[1], xsrc, rb_stride);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+        for (int p = 0; p < NP; ++p) {
+            pair_natural(w[2 * p], w[2 * p + 1]);
+            split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+        }
     }
     for (int rb0 = 0; rb0 < RB_p; rb0 += RBM) {
         const int gn = min(RBM, RB_p - rb0);
@@ -1268,8 +1404,28 @@ __device__ __forceinline__ void q3_body(const float4* __restrict__ wp4, const i3
         for (int g = 0; g < RBM; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        if (rb0) x3_load<NP, NP>(xq[0], xsrc, (int64_t)rb0 * rb_stride);
-        x3_tile_job<NP, RBM, NP>(wp, xq, xsrc, rb_stride, rb0, gn, acc);
+        if (rb0) {
+            x3_load<NP, NP>(xq[0], xsrc, (int64_t)rb0 * rb_stride);
+            if (ALL && RBM == 2 && gn > 1) x3_load<NP, NP>(xq[1], xsrc, (int64_t)(rb0 + 1) * rb_stride);
+        }
+        if constexpr (ALL && RBM == 2) {
+            if (gn > 1) {               // two row blocks = two independent accumulator chains, interleaved term by term
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+#define MELLOW_Q3_TERM(PW, PX) MELLOW_BF16(wp[p][PW], xq[0][p][PX], acc[0]); MELLOW_BF16(wp[p][PW], xq[1][p][PX], acc[1]);
+                    MELLOW_Q3_TERM(2, 0) MELLOW_Q3_TERM(0, 2) MELLOW_Q3_TERM(1, 1) MELLOW_Q3_TERM(1, 0) MELLOW_Q3_TERM(0, 1) MELLOW_Q3_TERM(0, 0)
+#undef MELLOW_Q3_TERM
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[0] = mma6(acc[0], wp[p], xq[0][p]);
+            }
+        } else if constexpr (ALL) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[0] = mma6(acc[0], wp[p], xq[0][p]);
+        } else {
+            x3_tile_job<NP, RBM, NP>(wp, xq, xsrc, rb_stride, rb0, gn, acc);
+        }
         if (rb0) __syncthreads();                 // the previous pass's epilogue has read `red`
 #pragma unroll
         for (int g = 0; g < RBM; ++g)
@@ -1327,6 +1483,9 @@ __global__ __launch_bounds__(Q3W * 64) void dec_qkv2x3_kernel(const float* __res
 #ifndef MELLOW_GU3_WAVES
 #define MELLOW_GU3_WAVES 6
 #endif
+#ifndef MELLOW_G3_ABL
+#define MELLOW_G3_ABL 0       // developer ablation (wrong results, timing only): 1 no pre-split store of h, 2 no MFMAs, 4 no activation loads, 8 no weight split, 16 no fp32 store of h
+#endif
 constexpr int GU3W = MELLOW_GU3_WAVES;
 // K4b (f32x3, any number of row blocks): see dec_gateup16_kernel.  x3 = x_mid in F3-16 (18 pairs x 2 row halves per block).
 // Writes h both as fp32 (guF: the last layer's fp32 down projection reads it) and pre-split (h3, F3-32 with 96 pairs).
@@ -1346,17 +1505,27 @@ __global__ __launch_bounds__(GU3W * 64) void dec_gateup3_kernel(const float* __r
     const i32x4* xsrc = x3 + (int64_t)T0 * 2 * 3 * 64 + lane;
     constexpr int64_t RBS = (int64_t)18 * 2 * 3 * 64;          // slots per row block
     {
-        const float4* wp4 = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * 36 + 2 * T0) * 64 + lane;
+        // P16N: [n16-tile][pair T][half][lane][4 floats]: lane (n, q) holds k = 32 T + 8 q + 4 half .. + 3 (1 KiB per wave load)
+        const float4* wp4 = reinterpret_cast<const float4*>(Wp16) + ((int64_t)nt * 18 + T0) * 128 + lane;
         float4 w[2 * NP];
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) w[i] = ldg_nt(wp4 + i * 64);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) xq[0][p][c / 3][c % 3] = xsrc[(p * 6 + c) * 64];          // block 0, requested with the weights
+            for (int c = 0; c < 6; ++c) xq[0][p][c / 3][c % 3] = (MELLOW_G3_ABL & 4) ? i32x4{c, p, 1, 2} : xsrc[(p * 6 + c) * 64];          // block 0, requested with the weights
+        if (RBM == 2 && RB_p > 1) {              // a two-block pass: both blocks' fragments at once
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xq[1][p][c / 3][c % 3] = (MELLOW_G3_ABL & 4) ? i32x4{c, p, 3, 2} : xsrc[RBS + (p * 6 + c) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+        for (int p = 0; p < NP; ++p) {
+            if (MELLOW_G3_ABL & 8) { wp[p][0] = __builtin_bit_cast(i32x4, w[2 * p]); wp[p][1] = __builtin_bit_cast(i32x4, w[2 * p + 1]); wp[p][2] = wp[p][0]; }
+            else split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
+        }
     }
     for (int rb0 = 0; rb0 < RB_p; rb0 += RBM) {
         const int gn = min(RBM, RB_p - rb0);
@@ -1378,13 +1547,19 @@ __global__ __launch_bounds__(GU3W * 64) void dec_gateup3_kernel(const float* __r
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) xq[0][p][c / 3][c % 3] = xsrc[(int64_t)rb0 * RBS + (p * 6 + c) * 64];
+            if (RBM == 2 && gn > 1) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) xq[1][p][c / 3][c % 3] = xsrc[(int64_t)(rb0 + 1) * RBS + (p * 6 + c) * 64];
+            }
         }
 #pragma unroll
         for (int g = 0; g < RBM; ++g) {
             acc0[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (g < gn) {
-                if (g + 1 < RBM && g + 1 < gn) {
+                if (RBM > 2 && g + 1 < RBM && g + 1 < gn) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -1392,8 +1567,11 @@ __global__ __launch_bounds__(GU3W * 64) void dec_gateup3_kernel(const float* __r
                 }
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    acc0[g] = mma6s(acc0[g], wp[p], xq[g & 1][p][0]);
-                    acc1[g] = mma6s(acc1[g], wp[p], xq[g & 1][p][1]);
+                    if (MELLOW_G3_ABL & 2) { acc0[g][0] += __int_as_float(wp[p][0][0] ^ xq[g & 1][p][0][0][0]); acc1[g][1] += __int_as_float(wp[p][2][1] ^ xq[g & 1][p][1][2][1]); continue; }
+                    // the two row halves are independent accumulator chains: term by term, alternating (a dependent MFMA waits ~2x its issue time)
+#define MELLOW_G3_TERM(PW, PX) MELLOW_BF16S(wp[p][PW], xq[g & 1][p][0][PX], acc0[g]); MELLOW_BF16S(wp[p][PW], xq[g & 1][p][1][PX], acc1[g]);
+                    MELLOW_G3_TERM(2, 0) MELLOW_G3_TERM(0, 2) MELLOW_G3_TERM(1, 1) MELLOW_G3_TERM(1, 0) MELLOW_G3_TERM(0, 1) MELLOW_G3_TERM(0, 0)
+#undef MELLOW_G3_TERM
                 }
             }
         }
@@ -1432,10 +1610,9 @@ __global__ __launch_bounds__(GU3W * 64) void dec_gateup3_kernel(const float* __r
                 h[r] = __fmul_rn(siluf_(gv * r2), uv * r2);
             }
             const float4 hv = make_float4(h[0], h[1], h[2], h[3]);
-            st_out(reinterpret_cast<float4*>(a.guF) + ((int64_t)rb * 192 + nt) * 64 + m + 32 * q, hv);
-            int eh;
-            const int64_t sl = f3_32_slot(rb, 96, m, 8 * nt + 4 * q, &eh);
-            f3_store4(a.h3, sl, eh, hv);
+            if (!(MELLOW_G3_ABL & 16)) st_out(reinterpret_cast<float4*>(a.guF) + ((int64_t)rb * 192 + nt) * 64 + m + 32 * q, hv);
+            const F3Quad hq = f3_split4(hv), ho = f3_partner(hq);     // threads (q = 0, q = 1) of a row hold the halves of one slot
+            if (!(MELLOW_G3_ABL & 1) && q == 0) f3_store8(a.h3, f3_32_slot(rb, 96, m, 8 * nt), hq, ho);
         }
     }
     kspan(a.dbg_seq, 1);
@@ -1795,13 +1972,16 @@ __global__ __launch_bounds__(192) void dec_final_norm_kernel(const float* __rest
         float4 y;
         y.x = __fmul_rn(wv.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(wv.y, __fmul_rn(v.y, r));
         y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
-        if (a.xn3) {                       // f32x3 lm_head: pre-split, F3-32
-            int eh;
-            const int64_t sl = f3_32_slot(b >> 5, 36, b & 31, xi * 4, &eh);
-            f3_store4(a.xn3, sl, eh, y);
-        } else {
-            reinterpret_cast<float4*>(a.xnF)[fi] = y;
+        if (!a.xn3) reinterpret_cast<float4*>(a.xnF)[fi] = y;
+    }
+    if (a.xn3) {                       // f32x3 lm_head: pre-split, F3-32; threads 2i, 2i + 1 hold the halves of one slot
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 144) {
+            y.x = __fmul_rn(wv.x, __fmul_rn(v.x, r)); y.y = __fmul_rn(wv.y, __fmul_rn(v.y, r));
+            y.z = __fmul_rn(wv.z, __fmul_rn(v.z, r)); y.w = __fmul_rn(wv.w, __fmul_rn(v.w, r));
         }
+        const F3Quad mine = f3_split4(y), other = f3_partner(mine);
+        if (tid < 144 && !(tid & 1)) f3_store8(a.xn3, f3_32_slot(b >> 5, 36, b & 31, tid * 4), mine, other);
     }
     kspan(a.dbg_seq, 1);
 }
@@ -1944,6 +2124,21 @@ __global__ __launch_bounds__(1024) void dec_compact_kernel(const DecArgs a, int 
     }
     if (tid == 0) *lp.n_compactions += 1;
 }
+// fp32 K/V pages -> their bf16 shadow (KV16; round to nearest even), 8 values per thread
+__global__ __launch_bounds__(256) void kv_to_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+        const bf16x8v o = {static_cast<__bf16>(a.x), static_cast<__bf16>(a.y), static_cast<__bf16>(a.z), static_cast<__bf16>(a.w),
+                           static_cast<__bf16>(b.x), static_cast<__bf16>(b.y), static_cast<__bf16>(b.z), static_cast<__bf16>(b.w)};
+        dst[i] = __builtin_bit_cast(uint4, o);
+    }
+}
+void launch_kv_to_bf16(const float* src, void* dst, int64_t n, hipStream_t s) {
+    const int64_t n8 = n >> 3;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(kv_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n8);
+}
 void launch_dec_compact(const DecArgs& a, int B, const LoopArgs& loop, hipStream_t s) {
     hipLaunchKernelGGL(dec_compact_kernel, dim3(1), dim3(1024), 0, s, a, B, loop);
 }
@@ -2016,8 +2211,12 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
     const dim3 grid(3, a.rows, DEC_TS), block(DA_WAVES * 64);
 #define MELLOW_DA(BLKV, FUSEDV, ONEV)                                                                                    \
-    hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
-                       (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a)
+    do {                                                                                                                 \
+        if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+                                       (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);               \
+        else hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+                                (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);                      \
+    } while (0)
     // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)
     if (a.RB == 1 && !a.blk_live) {
         if (fused) MELLOW_DA(false, true, true); else MELLOW_DA(false, false, true);
@@ -2165,14 +2364,38 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
             else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
                    hipLaunchKernelGGL((dec_head3_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
         } while (0)
+#ifndef MELLOW_H3_RESIDENT
+#define MELLOW_H3_RESIDENT 1
+#endif
+#ifndef MELLOW_H3R_D1
+#define MELLOW_H3R_D1 2
+#endif
+#ifndef MELLOW_H3R_D2
+#define MELLOW_H3R_D2 2
+#endif
+#ifndef MELLOW_H3R_D4
+#define MELLOW_H3R_D4 1
+#endif
+#define MELLOW_H3R(GV, DV)                                                                                                \
+        do {                                                                                                              \
+            const size_t lds = (size_t)36 * 3 * 64 * 16;                                                                  \
+            if (a.blk_live) { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<GV, DV, true>), lds);  \
+                              hipLaunchKernelGGL((dec_head3r_kernel<GV, DV, true>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
+            else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<GV, DV, false>), lds);             \
+                   hipLaunchKernelGGL((dec_head3r_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
+        } while (0)
+        if (MELLOW_H3_RESIDENT) {
+            if (a.RB == 1) MELLOW_H3R(1, MELLOW_H3R_D1); else if (a.RB == 2) MELLOW_H3R(2, MELLOW_H3R_D2); else MELLOW_H3R(4, MELLOW_H3R_D4);
+        } else
         if (a.RB == 1) MELLOW_H3(1, MELLOW_H3_D1); else if (a.RB == 2) MELLOW_H3(2, MELLOW_H3_D2); else MELLOW_H3(4, MELLOW_H3_D4);
+#undef MELLOW_H3R
 #undef MELLOW_H3
         return;
     }
     if ((a.x3 & DEC_X3_HEAD) && !wscale) {          // f32x3 mode on caller rows (taps): operands split in registers
         const dim3 grid(vocab / 32), block(LM3_WAVES * 64);
-        if (a.blk_live) hipLaunchKernelGGL((dec_fullk3_kernel<true, false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
-        else hipLaunchKernelGGL((dec_fullk3_kernel<false, false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
+        if (a.blk_live) hipLaunchKernelGGL((dec_fullk3_kernel<true>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
+        else hipLaunchKernelGGL((dec_fullk3_kernel<false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
         return;
     }
     const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
@@ -2274,6 +2497,22 @@ __global__ void pack_weight16_kernel(const float* __restrict__ w, int N, int K, 
         const int n = nt * 16 + (lane & 15), k0 = k16 * 16 + 4 * (lane >> 4);
         reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(w + (int64_t)n * K + k0);
     }
+}
+// P16N packing (f32x3 gate/up): out[nt][T][half][lane][4] = W[nt*16 + (lane&15)][T*32 + 8*(lane>>4) + 4*half + j]
+__global__ void pack_weight16n_kernel(const float* __restrict__ w, int N, int K, float* __restrict__ out) {
+    const int64_t total = (int64_t)(N / 16) * (K / 32) * 128;            // float4 units
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), half = (int)((i >> 6) & 1);
+        const int64_t tile = i >> 7;
+        const int T = (int)(tile % (K / 32)), nt = (int)(tile / (K / 32));
+        const int n = nt * 16 + (lane & 15), k0 = T * 32 + 8 * (lane >> 4) + 4 * half;
+        reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(w + (int64_t)n * K + k0);
+    }
+}
+void launch_pack_weight16n(const float* w, int N, int K, float* out, hipStream_t s) {
+    const int64_t total = (int64_t)(N / 16) * (K / 32) * 128;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight16n_kernel, dim3(blocks), dim3(256), 0, s, w, N, K, out);
 }
 void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s) {
     const int64_t total = (int64_t)(N / 16) * (K / 16) * 64;

@@ -89,6 +89,7 @@ struct LMLayerW {
     Packed qkv, o, gateup, down;       // prefill (plain weights, P-layout); `down` is also the decode operand
     Packed qkv_f, gateup_f;            // decode: RMSNorm weight folded into the columns (W'[n][k] = W[n][k]*ln[k])
     float* o16 = nullptr;              // decode: P16 layout (16-row tiles) for the complete-output o_proj
+    float* gu16n = nullptr;            // decode, f32x3 layer kernels: the same tiles in P16N order (eight consecutive k per lane)
     float* gu16 = nullptr;             // decode: folded gate/up, P16 layout, tile = 8 gate rows + the 8 matching up rows
     // decode, layers >= 1: [W'_l | W'_l Wd_{l-1}] (960 x (576 + 1536), P-layout, the product formed in fp64 at load time): the
     // operand of dec_qkv2_kernel, which runs the down projection of layer l-1 and the q/k/v projection of layer l as one launch
@@ -151,6 +152,8 @@ struct mellow_engine {
     };
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
+    Buf kcache16, vcache16;      // fp8 mode: bf16 shadow of the pages for the decode step (half the floats of kcache / vcache)
+    bool kv16 = false;           // MELLOW_FP8_KV16=1 (opt-in, measured and not adopted as the default: DESIGN 6b)
     Buf lm_xn3, lm_o3, lm_h3;                  // f32x3 mode: the GEMM inputs of LM prefill, pre-split by their producers (APB order)
     Buf lm_ssq;                                // ... and the per-row sum-of-squares partials of the residual stream (norm-free chaining)
     Buf dec;                                   // one arena for the decode-step buffers (DecArgs)

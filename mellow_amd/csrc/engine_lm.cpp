@@ -26,6 +26,10 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         e->kv_Tmax = Tmax;
         CHK(ensure(e, e->kcache, kv_layer_floats(e) * e->cfg.num_layers));
         CHK(ensure(e, e->vcache, kv_layer_floats(e) * e->cfg.num_layers));
+        if (e->kv16) {
+            CHK(ensure(e, e->kcache16, kv_layer_floats(e) * e->cfg.num_layers / 2));
+            CHK(ensure(e, e->vcache16, kv_layer_floats(e) * e->cfg.num_layers / 2));
+        }
         // the decode attention loads whole key groups before it knows the position and masks them afterwards
         // (weight 0 x value): never-written page slots must hold finite numbers
         HIPCHK(hipMemsetAsync(e->kcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
@@ -46,7 +50,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         const size_t o_ssq = take((size_t)Bp * 40), o_gu = take(RB * 192 * 256), o_xmidF16 = take(n_x);
         // f32x3 layer kernels: 6-byte pre-split images of x_mid (two fragment orders) and of h
         const bool x3l = (e->dec_x3 & DEC_X3_GATEUP) && (e->dec_x3 & DEC_X3_QKV) && (int)RB >= e->dec_x3_min_rb && !e->fp8_decode &&
-                         e->layers.size() > 1 && e->layers[1].qkv2 != nullptr;
+                         e->layers.size() > 1 && e->layers[1].qkv2 != nullptr && e->layers[1].gu16n != nullptr;
         const size_t o_x3a = take(x3l ? n_x * 3 / 2 : 0), o_x3b = take(x3l ? n_x * 3 / 2 : 0), o_h3 = take(x3l ? RB * 192 * 256 * 3 / 2 : 0);
         const bool fresh = e->dec.cap < off;
         CHK(ensure(e, e->dec, off));
@@ -62,6 +66,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         DecArgs& a = e->da;
         a.rows = Bp; a.RB = (int)RB; a.Tmax = Tmax; a.eps = e->cfg.rms_norm_eps; a.d_pos = e->d_pos; a.inc_pos = 0; a.first = 0;
         a.a8 = e->fp8_decode_act ? 1 : 0;
+        a.kv16 = e->kv16 ? 1 : 0;
         a.x3 = e->dec_x3;
         a.blk_live = nullptr;                               // mellow_generate turns the per-block early exit on per call
         a.row_of_slot = nullptr;
@@ -250,6 +255,12 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
         if (last) break;
     }
     CHK(join.run());
+    if (e->kv16 && !all_positions) {
+        // fp8 mode: the decode step streams a bf16 shadow of the pages (whole pages: the cleared tails travel with them)
+        ProfScope ps(e, PF_MISC, 0, 3.0 * kv_layer_floats(e) * NL * 4);
+        launch_kv_to_bf16(e->kcache.p, e->kcache16.p, (int64_t)(kv_layer_floats(e) * NL), s);
+        launch_kv_to_bf16(e->vcache.p, e->vcache16.p, (int64_t)(kv_layer_floats(e) * NL), s);
+    }
     if (all_positions) {        // x = the hidden states after all layers, every position (mellow_lm_forward_logits)
         HIPCHK(hipGetLastError());
         return 0;
@@ -288,8 +299,9 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
 #endif
     for (int l = l_begin; l < l_end; ++l) {
         const LMLayerW& w = e->layers[same_w ? 0 : l];
-        float* kc = e->kcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
-        float* vc = e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
+        // (KV16: the bf16 shadow pages; a layer's pages are half as many floats)
+        float* kc = e->kv16 ? e->kcache16.p + kv_layer_floats(e) / 2 * (same_kv ? 0 : l) : e->kcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
+        float* vc = e->kv16 ? e->vcache16.p + kv_layer_floats(e) / 2 * (same_kv ? 0 : l) : e->vcache.p + kv_layer_floats(e) * (same_kv ? 0 : l);
         const int kcd = l == l_begin ? 0 : DEC_KC_DOWN;   // the first layer of the range starts from a materialised x
         // fused_in: this layer's q/k/v slabs (and the down slabs of x_new) were written by the previous layer's dec_qkv2 launch
         // The fused launch pays at ONE row block (B <= 32: 46.8 ms per 63 steps against 49.9 with the five-launch layer) and loses
@@ -320,7 +332,7 @@ int enqueue_decode_layer_range(mellow_engine* e, int B, int l_begin, int l_end, 
         if (!(skip & 8))
         { ProfScope ps(e, PF_SKINNY, 2.0 * Bp * 576.0 * 3072.0, 576.0 * 3072.0 * 4);
           if (w.gu8) launch_dec_gateup(da(3), w.gu8, s, w.gu_sc);
-          else if (x3l) launch_dec_gateup3(da(3), w.gu16, s);
+          else if (x3l) launch_dec_gateup3(da(3), w.gu16n, s);
           else launch_dec_gateup(da(3), w.gu16, s); }
         const LMLayerW* nx = (l + 1 < l_end && !same_w) ? &e->layers[l + 1] : nullptr;
         if (nx && ((nx->qkv2 && fuse_rb) || nx->q2h8)) {

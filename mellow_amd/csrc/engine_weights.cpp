@@ -88,13 +88,14 @@ static int make_dec_fp8(mellow_engine* e, const float* Wp, int tiles, int slots,
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
-static int make_packed16(mellow_engine* e, const float* w, int N, int K, float** out) {
-    if (N % 16 || K % 16) return fail("P16 packing needs N and K multiples of 16");
+static int make_packed16(mellow_engine* e, const float* w, int N, int K, float** out, bool natural = false) {
+    if (N % 16 || K % (natural ? 32 : 16)) return fail("P16 packing needs N and K multiples of 16 (32 for the P16N order)");
     float* d0 = nullptr;
     HIPCHK(hipMalloc(&d0, (size_t)N * K * sizeof(float)));
     HIPCHK(hipMemcpy(d0, w, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice));
     CHK(dev_alloc(e, out, (size_t)N * K));
-    launch_pack_weight16(d0, N, K, *out, e->stream);
+    if (natural) launch_pack_weight16n(d0, N, K, *out, e->stream);
+    else launch_pack_weight16(d0, N, K, *out, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(d0));
@@ -360,6 +361,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                     memcpy(il.data() + (size_t)(2 * t + 1) * 8 * H, uf.data() + (size_t)t * 8 * H, (size_t)8 * H * 4);
                 }
                 CHK(make_packed16(e, il.data(), 2 * I, H, &w.gu16));
+                if (e->f32x3_terms && fuse && !e->fp8_decode) CHK(make_packed16(e, il.data(), 2 * I, H, &w.gu16n, true));    // f32x3 layer kernels (row blocks >= dec_x3_min_rb)
             }
             CHK(make_packed16(e, get(e, p + "self_attn.o_proj.weight")->f(), H, 576, &w.o16));
         }

@@ -170,6 +170,7 @@ struct DecArgs {
     // token record, its stop flag).  dec_compact_kernel repacks the rows that are still running into the lowest slots
     // whenever that empties a whole 32-row block.
     const int32_t* row_of_slot = nullptr;
+    int kv16 = 0;                  // fp8 mode: the K/V page pointers of launch_dec_attn address the bf16 shadow pages (decode.hip, KV16)
     int a8 = 0;                    // fp8 mode: launches that get e4m3 weights also quantise their activations (fp8 matrix pipe)
     int x3 = 0;                    // f32x3 mode: bit mask of the decode GEMM launches that run on the bf16 matrix pipe with operands split in
                                    // registers (DEC_X3_*; decode.hip); 0 = the exact fp32 MFMA kernels
@@ -183,12 +184,14 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp_folded, int K8p, int kcd, 
 void launch_pack_dec_fp8(const float* Wp, int tiles, int slots_per_tile, int rows_per_tile, void* out, float* scale, hipStream_t s);
 // fused = the projected values come from launch_dec_qkv2 (Q2_NPQ slabs; the attention also forms x_new from the down slabs)
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s);
+// n fp32 values (n % 8 == 0) -> bf16, round to nearest even (the K/V shadow pages of the fp8 mode)
+void launch_kv_to_bf16(const float* src, void* dst, int64_t n, hipStream_t s);
 // down projection of a layer + q/k/v projection of the next one: Wq2 = P-layout [30][Q2_K8] of [W'_{l+1} | W'_{l+1} Wd_l],
 // Wd = this layer's down weight in P-layout (K8p = 192)
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
 // f32x3 forms for any number of row blocks (operands a.xmid3_32 / a.h3 / a.xmid3_16 pre-split by the o_proj / gate-up launches)
 void launch_dec_qkv2x3(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
-void launch_dec_gateup3(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s);
+void launch_dec_gateup3(const DecArgs& a, const float* Wp16n_folded_pairs, hipStream_t s);
 // the same launch on e4m3 weights: the unfused layer's q/k/v copy (72 k-tiles per n-tile), the composed W' Wd (192) and the
 // down copy, one scale per packed row each (launch_pack_dec_fp8)
 void launch_dec_qkv2_w8(const DecArgs& a, const float* Wx8, const float* sc_x, const float* Wh8, const float* sc_h,
@@ -231,6 +234,8 @@ void launch_dec_compact(const DecArgs& a, int B, const LoopArgs& loop, hipStream
 void launch_dec_load_rows(const DecArgs& a, int B, const float* in, int64_t ld, const int32_t* row_ids, int T_last,
                           int n_src /* rows of `in` that row_ids may address */, hipStream_t s);
 void launch_pack_weight16(const float* w, int N, int K, float* out, hipStream_t s);
+// the same 16-row tiles with eight consecutive k per lane (f32x3 gate/up, decode.hip P16N); K % 32 == 0
+void launch_pack_weight16n(const float* w, int N, int K, float* out, hipStream_t s);
 // developer instrumentation: device buffer of 64 uint64 slots stamped by workgroup 0 of the decode kernels (null = off)
 void set_kernel_debug_buffer(uint64_t* p);
 void set_gemm_debug_buffer(uint64_t* p);

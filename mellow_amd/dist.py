@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -38,6 +40,13 @@ def examples_signature(examples) -> bytes:
             if isinstance(item, (str, bytes)) or hasattr(item, "__fspath__"):
                 b = item if isinstance(item, bytes) else str(item).encode()
                 h.update(b"s" + len(b).to_bytes(8, "little") + b)
+                # a path that names a file on this rank: its size and mtime go in too, so that same-named but different files on
+                # different nodes do not pass for the same example (a prompt string is not a file: nothing is added)
+                try:
+                    st = os.stat(item)
+                    h.update(b"f" + int(st.st_size).to_bytes(8, "little") + int(st.st_mtime_ns).to_bytes(16, "little", signed=True))
+                except (OSError, ValueError, TypeError):
+                    pass
             else:
                 a = np.ascontiguousarray(torch.as_tensor(item).detach().cpu().numpy(), dtype=np.float32)
                 h.update(b"a" + repr(a.shape).encode() + a.tobytes())
@@ -56,7 +65,26 @@ def agree_on_examples(sig: bytes) -> None:
     _agree_calls += 1
     c = _agree_calls                                     # every rank makes the same sequence of data-parallel calls
     store.set(f"mellow_amd/examples/{c}/{rank}", sig)
-    sigs = [bytes(store.get(f"mellow_amd/examples/{c}/{r}")) for r in range(world)]      # get() waits for the key
+    # The key carries this process's COUNT of data-parallel calls: a rank that raised before reaching an earlier call (an audio
+    # file missing on one node is enough), or that drives a second wrapper differently, is one call behind for good.  Waiting for
+    # it with the store's default timeout (300 s) and an opaque error helps nobody: wait explicitly, briefly, and say what happened.
+    import datetime
+    timeout_s = float(os.environ.get("MELLOW_DP_AGREE_TIMEOUT_S", "120"))
+    keys = [f"mellow_amd/examples/{c}/{r}" for r in range(world)]
+    try:
+        store.wait(keys, datetime.timedelta(seconds=timeout_s))
+    except Exception as e:
+        missing = []
+        for r, k in enumerate(keys):
+            try:
+                if not store.check([k]):
+                    missing.append(r)
+            except Exception:
+                missing.append(r)
+        raise RuntimeError(f"data_parallel generate(): rank(s) {missing} did not reach their data-parallel call #{c} within {timeout_s:.0f} s "
+                           "(every rank must make the same sequence of data-parallel generate() calls; a rank that raised before "
+                           "one of them, or skipped it, is out of step -- restart the group).  MELLOW_DP_AGREE_TIMEOUT_S sets the wait.") from e
+    sigs = [bytes(store.get(k)) for k in keys]
     if c > 1:          # every rank has published call c, hence finished reading call c - 1
         try:
             store.delete_key(f"mellow_amd/examples/{c - 1}/{rank}")

@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
         "mellow_last_row_repacks": (ci, [vp]),
         "mellow_stft_is_fft": (ci, [vp]),
         "mellow_prefill_parts": (ci, [vp]),
+        "mellow_abi_minor": (ci, []),
         "mellow_engine_set_precision": (ci, [vp, ci]),
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
@@ -113,7 +114,7 @@ EXPORTED_SYMBOLS = (
     "mellow_engine_num_required", "mellow_engine_required_key", "mellow_generate", "mellow_logmel",
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
-    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft", "mellow_prefill_parts",
+    "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft", "mellow_prefill_parts", "mellow_abi_minor",
     "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_debug_dec_head", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
 )
 

@@ -21,6 +21,8 @@ What it reports (JSON on stdout, non-zero exit on a hard failure):
                    per-step teacher-forced |logit| difference; histogram of the oracle's top-2 logit gaps (how much margin the
                    real weights leave: the synthetic checkpoint's minimum is 0.011-0.043).
   4. `fp8`         BASELINE config 5 mode against the f32 engine: first-token / position-wise agreement, mean common prefix (report).
+  5. `resampler`   torchaudio's BINARY, when importable on that box, against the independent fp64 oracle of its published algorithm
+                   and against the product's host resampler (44.1 / 48 kHz -> 32 kHz) -- HARD when outside the fp32 bound.
 """
 from __future__ import annotations
 
@@ -51,6 +53,44 @@ class StubTokenizer:
 
     def decode(self, ids):
         return " ".join("<|endoftext|>" if int(i) == 0 else f"t{int(i)}" for i in ids)
+
+
+def check_resampler():
+    """torchaudio is absent from the build container, so the resampler (reference wrapper.py:144-148, 44.1 -> 32 kHz) is
+    pinned to torchaudio's PUBLISHED algorithm (oracle/resample_oracle.py, fp64) only.  On a box that has the package this settles
+    it against the binary: seeded noise + two tones, 1.7 s at 44.1 kHz and at 48 kHz."""
+    from mellow_amd import audio as A
+    from oracle import resample_oracle as R
+    out = {}
+    try:
+        import torchaudio  # noqa: F401
+        from torchaudio.transforms import Resample
+    except Exception as e:      # not an error: report and go on
+        Resample = None
+        out["torchaudio"] = f"not importable here ({type(e).__name__}): the binary stays unpinned on this box"
+    rng = np.random.default_rng(11)
+    for orig in (44100, 48000):
+        n = int(1.7 * orig)
+        t = np.arange(n) / orig
+        x = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 5200 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+        ref, bound = R.resample(x, orig, 32000, return_bound=True)
+        tol = R.fp32_tolerance(bound, orig, 32000)
+        ours = A.resample(torch.from_numpy(x)[None], orig, 32000)[0].numpy()
+        entry = {"host_twin_vs_fp64_oracle_max_abs": float(np.abs(ours - ref).max()), "fp32_bound_max": float(tol.max()),
+                 "host_twin_within_bound": bool((np.abs(ours - ref) <= tol).all())}
+        if Resample is not None:
+            ta = Resample(orig, 32000)(torch.from_numpy(x)[None])[0].numpy()
+            entry["torchaudio_len_equal"] = bool(ta.shape == ref.shape)
+            if ta.shape == ref.shape:
+                entry["torchaudio_vs_fp64_oracle_max_abs"] = float(np.abs(ta - ref).max())
+                entry["torchaudio_within_bound"] = bool((np.abs(ta - ref) <= tol).all())
+                entry["torchaudio_vs_host_twin_max_abs"] = float(np.abs(ta - ours).max())
+            if not entry.get("torchaudio_within_bound", False):
+                out["hard"] = f"torchaudio's Resample({orig} -> 32000) is outside the fp32 bound of the published algorithm: {entry}"
+        if not entry["host_twin_within_bound"]:
+            out["hard"] = f"the host resampler is outside the fp32 bound at {orig} Hz: {entry}"
+        out[str(orig)] = entry
+    return out
 
 
 def check_lm_config(dirs):
@@ -200,6 +240,10 @@ def main():
     report["fp8"] = {"first_token_agreement": float((t8[:, 0] == t32[:, 0]).mean()), "position_wise_agreement": float((t8 == t32).mean()),
                      "mean_common_prefix": float(np.mean(common)), "rows_identical": float(np.mean([c == L for c in common])),
                      "note": "BASELINE config 5 numerics are not bit-comparable with the fp32 path; this is the figure to quote for it"}
+    # ---- resampler: torchaudio's BINARY (when this box has it) against the independent fp64 oracle and the product's host twin ----
+    report["resampler"] = check_resampler()
+    if report["resampler"].get("hard"):
+        hard_fail.append(report["resampler"]["hard"])
     # the text path of the public API on the first example (what a user sees)
     texts = {m: wrappers[m]._generate_batch(torch.from_numpy(a1[:1]), torch.from_numpy(a2[:1]), torch.from_numpy(ids[:1]), entry_length=L)[0]
              for m in ("f32", "f32x3", "fp8")}

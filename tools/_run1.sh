@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r05_gputest_a.log 2>&1; tail -15 gpurun_out/r05_gputest_a.log
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r05_gputest_b.log 2>&1; tail -8 gpurun_out/r05_gputest_b.log
