@@ -39,8 +39,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 matrix peak (same guide); the 32x32x16 fp8 form used here sustains 2460
 PEAK_HBM_GBS = 8000.0
 PEAK_F32X3_TFLOPS = 2500.0 / 6.0   # f32x3 mode: six bf16 MFMA products per fp32 product on the 2.5 PF dense bf16 pipe
-PMC_TRAFFIC_FILE = "r04_pmc_gemm_traffic.json"          # dense GEMM family (tools/pmc_traffic.py gemm)
-PMC_DECODE_FILE = "r04_pmc_decode_traffic.json"         # decode step (tools/pmc_traffic.py decode)
+PMC_TRAFFIC_FILE = "r05_pmc_gemm_traffic.json"          # dense GEMM family (tools/pmc_traffic.py gemm)
+PMC_DECODE_FILE = "r05_pmc_decode_traffic.json"         # decode step (tools/pmc_traffic.py decode)
 FFT_GFLOP_PER_CLIP = 0.051         # algorithmic cost of the STFT; the kernel runs it as a dense DFT GEMM (2.10 GF/clip)
 
 # algorithmic work per response at max_len = 64, prefix 389
@@ -554,7 +554,7 @@ def main():
         # HBM-bound, priced by the ALGORITHMIC bytes of SURVEY 8d; `traffic` = what the memory side actually moved per step (PMC)
         out["roofline"] = {
             "kernel": "one decode step (hipGraph replay): dec_qkv + 30 x dec_attn + 30 x (dec_oproj | dec_gateup16) + 29 x dec_qkv2 + dec_down "
-                      "+ final norm, lm_head, arg-max; the dominant phase of the pass by time",
+                      "+ final norm, lm_head (f32x3 mode: dec_head3r_kernel, weights streamed once on the bf16 pipe), arg-max; the dominant phase of the pass by time",
             "bound": "hbm", "achieved": round(dec_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(dec_gbs / PEAK_HBM_GBS, 4), "traffic": dec_traffic, "traffic_unit": dec_traffic_note + " per step",
             "launches": L - 1, "avg_launch_us": round(phases["decode_ms"] * 1e3 / max(1, L - 1), 2),

@@ -2368,10 +2368,10 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
 #define MELLOW_H3_RESIDENT 1
 #endif
 #ifndef MELLOW_H3R_D1
-#define MELLOW_H3R_D1 2
+#define MELLOW_H3R_D1 1
 #endif
 #ifndef MELLOW_H3R_D2
-#define MELLOW_H3R_D2 2
+#define MELLOW_H3R_D2 1
 #endif
 #ifndef MELLOW_H3R_D4
 #define MELLOW_H3R_D4 1

@@ -1,8 +1,8 @@
-# Everything under profiles/r04_* in one GPU call (gpurun -- bash tools/collect_profiles.sh).  PMC passes run alone
+# Everything under profiles/r05_* in one GPU call (gpurun -- bash tools/collect_profiles.sh).  PMC passes run alone
 # (--pmc only, no trace domains); FETCH_SIZE and WRITE_SIZE in separate passes.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r04
+R=r05
 O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 # --- PMC: HBM-side traffic of the GEMM family (per launch) and of the decode step (per step) ---
@@ -42,5 +42,11 @@ cp $O/stats1/st_kernel_stats.csv $O/bench_onechain_kernel_stats.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
 python tools/trace_summary.py $O/trace_dec/tr_kernel_trace.csv 40 > $O/decode_step_timeline.txt 2>&1
 timeout 400 python tools/fp8_agreement.py structured 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement.txt
+# --- decode phase by batch size: the f32x3 multi-row-block path against the fp32 kernels replicated per row block ---
+{ echo "# decode phase of one generate() pass, 63 steps, f32x3 mode (tools/decode_probe.py); x3 = f32x3 forms of the layer GEMM launches from two row blocks on + the streaming lm_head; fp32 = MELLOW_DECODE_X3=0 (round 4's kernels)";
+  for B in 32 64 128 256 512; do echo "B=$B x3  : $(timeout 300 python tools/decode_probe.py $B 64 2>&1 | grep decode_ms)"; echo "B=$B fp32: $(MELLOW_DECODE_X3=0 timeout 300 python tools/decode_probe.py $B 64 2>&1 | grep decode_ms)"; done; } > $O/decode_batch_table.txt
+timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec64 -o tr --output-format csv -- python tools/decode_probe.py 64 64 > /dev/null 2>&1
+python tools/trace_summary.py $O/trace_dec64/tr_kernel_trace.csv 40 > $O/decode_step_timeline_b64.txt 2>&1
+rm -rf $O/trace_dec64
 rm -rf $O/stats $O/stats1 $O/pf $O/pw $O/df $O/dw $O/pm $O/trace_dec
 ls -la $O

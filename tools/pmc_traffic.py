@@ -16,7 +16,8 @@ from bench import kernel_source_sha16  # noqa: E402  (bench.py refuses to print 
 GEMM = ("gemm_f32_kernel", "gemm_x3p_kernel", "gemm_x3q_kernel", "gemm_x3w_kernel", "gemm_bf16x3f_kernel", "stft_fft_power_kernel",
         "splitk_finish_kernel")          # (the second launch of a split-K GEMM: its bytes count, it is not a launch of its own)
 DECODE = ("dec_qkv_kernel", "dec_qkv2_kernel", "dec_attn_kernel", "dec_oproj_kernel", "dec_gateup16_kernel", "dec_down_kernel",
-          "dec_final_norm_kernel", "dec_fullk_kernel", "dec_argmax_kernel", "dec_compact_kernel")
+          "dec_final_norm_kernel", "dec_fullk_kernel", "dec_fullk3_kernel", "dec_head3_kernel", "dec_head3r_kernel", "dec_qkv2x3_kernel",
+          "dec_gateup3_kernel", "dec_argmax_kernel", "dec_compact_kernel")
 
 
 def family(path, counter, names):
@@ -59,7 +60,7 @@ if mode == "gemm":
         "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / nf,
     })
 else:
-    steps = pf["dec_fullk_kernel"][0]          # one lm_head launch per decode step (the prefill's last-position step included)
+    steps = pf["dec_argmax_kernel"][0]         # one arg-max launch per decode step (the prefill's last-position step included)
     out.update({
         "kernel": "every kernel of the decode step (dec_*), summed per step",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_decode.py (one call at B=32, max_len 6: "
