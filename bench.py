@@ -300,7 +300,7 @@ def alt_modes(B: int, L: int, headline: str):
                 e.generate(b1d, b2d, bid, max_len=L, stop_id=0, ignore_stop=True)
             torch.cuda.synchronize()
             ph8 = e.last_phase_ms()
-            kv16 = os.environ.get("MELLOW_FP8_KV16", "0") == "1"
+            kv16 = os.environ.get("MELLOW_FP8_KV16", "1") != "0"
             b8 = decode_algorithmic_bytes_fp8(128, L) if kv16 else (decode_algorithmic_bytes(128, L) - (L - 1) * 134_515_008 * 3.0)
             res["fp8_b128"] = {"batch": 128, "value": round(2 * 128 / (time.perf_counter() - t0), 2), "unit": "responses/s",
                                "phase_ms": {k: round(v, 2) for k, v in ph8.items()},
@@ -494,6 +494,11 @@ def main():
         tf = flops_alg / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         tf_dense = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         dec_bytes = decode_algorithmic_bytes(B, L)
+        if args.precision == "fp8":
+            # the fp8 mode is priced on ITS OWN bytes (e4m3 weights 134.5 MB per step; K/V as the mode stores them):
+            # pricing it on the fp32 mode's 538 MB + 46,080 B per token would flatter it
+            kv16 = os.environ.get("MELLOW_FP8_KV16", "1") != "0"
+            dec_bytes = decode_algorithmic_bytes_fp8(B, L) if kv16 else decode_algorithmic_bytes(B, L) - (L - 1) * 134_515_008 * 3.0
         dec_gbs = dec_bytes / (phases["decode_ms"] * 1e-3) / 1e9 if phases["decode_ms"] > 0 else 0.0
         # whole-path two-phase roofline: t_roof = F_dense/P_mfma + Bytes_decode/BW_hbm
         fp8 = args.precision == "fp8"
@@ -560,7 +565,9 @@ def main():
             "launches": L - 1, "avg_launch_us": round(phases["decode_ms"] * 1e3 / max(1, L - 1), 2),
             "bytes_per_launch": round(dec_bytes / max(1, L - 1)),
             "share_of_pass": round(phases["decode_ms"] / ms_per_step, 3),
-            "note": "achieved = algorithmic bytes per step (538.06 MB of fp32 weights + 46,080 B per cached token per example, SURVEY 8d) "
+            "note": ("achieved = algorithmic bytes per step OF THE fp8 MODE (134.5 MB of e4m3 weights + 23,040 B of bf16 shadow pages per cached token "
+                     "per example; fp32 pages with MELLOW_FP8_KV16=0) " if args.precision == "fp8" else
+                     "achieved = algorithmic bytes per step (538.06 MB of fp32 weights + 46,080 B per cached token per example, SURVEY 8d) ") +
                     "/ average step time, HIP events around the decode phase of the timed pass on the engine's stream",
         }
         out["roofline_decode"] = out["roofline"]                 # the name earlier rounds used

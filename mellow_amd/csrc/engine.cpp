@@ -449,7 +449,7 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     e->fp8_decode_act = e->fp8_decode && !(fa && fa[0] == '0');
     e->fp8_prefill = !(fp && fp[0] == '0');
     const char* fk = getenv("MELLOW_FP8_KV16");
-    e->kv16 = e->fp8_decode && fk && fk[0] == '1';       // opt-in: measured -7.5 % decode time at B = 128 for 0.81 -> 0.72 token agreement
+    e->kv16 = e->fp8_decode && !(fk && fk[0] == '0');    // fp8 mode: bf16 shadow pages for the decode step; MELLOW_FP8_KV16=0: fp32 pages
     e->f32x3_terms = 0;
     if (mode == MELLOW_PRECISION_F32X3) {
         // six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64

@@ -1,3 +1,9 @@
-mkdir -p gpurun_out; rm -f gpurun_out/trace_*.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "f32x3 and (lm_prefill_and_decode or generate_tokens or batch32_matches or batch64_matches or multi_row_block or row_block_early_exit or large_batches)" > gpurun_out/t1.log 2>&1; tail -3 gpurun_out/t1.log
-for v in base h3old h3r_d1 h3r_d3 h3r_nw4; do lib=mellow_amd/lib/ab/libmellow_hip_$v.so; [ $v = base ] && lib=mellow_amd/lib/libmellow_hip.so; for B in 32 64 128; do MELLOW_HIP_LIB=$lib bash tools/trace_decode.sh ${v}_$B $B > /dev/null 2>&1; echo "== $v B=$B"; grep -E "head3" gpurun_out/trace_${v}_$B.txt; done; done
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fp8" > gpurun_out/t1.log 2>&1; tail -4 gpurun_out/t1.log
+timeout 300 python bench.py --steps 3 --warmup 1 --preset configs4 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > gpurun_out/r05_bench_configs4.json 2>/dev/null
+timeout 300 python bench.py --steps 5 --warmup 2 --precision fp8 --no-cpu-baseline --no-alt-modes --no-b64 --no-configs3 --inflight 0 > gpurun_out/r05_bench_fp8.json 2>/dev/null
+python - <<'PY'
+import json
+for f in ("gpurun_out/r05_bench_configs4.json","gpurun_out/r05_bench_fp8.json"):
+    d=json.load(open(f)); print(f, d["value"], d["phase_ms"], d.get("roofline",{}) and d["roofline"].get("frac"))
+PY
