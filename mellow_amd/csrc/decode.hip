@@ -1096,6 +1096,18 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
 #ifndef MELLOW_H3_NW
 #define MELLOW_H3_NW 8
 #endif
+#ifndef MELLOW_H3_RESIDENT
+#define MELLOW_H3_RESIDENT 1      // the lm_head with the activations resident in LDS (dec_head3r_kernel); 0 = the chunked stage (dec_head3_kernel)
+#endif
+#ifndef MELLOW_H3R_D1
+#define MELLOW_H3R_D1 1           // weight chunks in flight per wave at 1 / 2 / >= 3 row blocks (2 and 3 measured slower)
+#endif
+#ifndef MELLOW_H3R_D2
+#define MELLOW_H3R_D2 1
+#endif
+#ifndef MELLOW_H3R_D4
+#define MELLOW_H3R_D4 1
+#endif
 #ifndef MELLOW_H3_D1
 #define MELLOW_H3_D1 1
 #endif
@@ -2258,6 +2270,19 @@ static void launch_dec_qkv2_any(const DecArgs& a, const float* Wx, int K8x, cons
 #undef MELLOW_Q2_MODES
 #undef MELLOW_Q2
 }
+// The launchers raise a kernel's dynamic-LDS limit on first use; a decode step is launched inside a stream capture, so the engine
+// calls this once per device beforehand (ensure_lm): every instantiation that needs more than 64 KiB.
+void dec_prepare_lds_attributes() {
+    const size_t head = (size_t)36 * 3 * 64 * 16, q4 = (size_t)Q3W * 4 * 16 * 64 * 4;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<1, MELLOW_H3R_D1, true>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<1, MELLOW_H3R_D1, false>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<2, MELLOW_H3R_D2, true>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<2, MELLOW_H3R_D2, false>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<4, MELLOW_H3R_D4, true>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<4, MELLOW_H3R_D4, false>), head);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_qkv2x3_kernel<true, 4>), q4);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_qkv2x3_kernel<false, 4>), q4);
+}
 void launch_dec_qkv2x3(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s) {
     const float* Wh = Wq2 + (size_t)72 * 64 * 4;
     const i32x4 *x3 = reinterpret_cast<const i32x4*>(a.xmid3_32), *h3 = reinterpret_cast<const i32x4*>(a.h3);
@@ -2364,18 +2389,6 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
             else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
                    hipLaunchKernelGGL((dec_head3_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
         } while (0)
-#ifndef MELLOW_H3_RESIDENT
-#define MELLOW_H3_RESIDENT 1
-#endif
-#ifndef MELLOW_H3R_D1
-#define MELLOW_H3R_D1 1
-#endif
-#ifndef MELLOW_H3R_D2
-#define MELLOW_H3R_D2 1
-#endif
-#ifndef MELLOW_H3R_D4
-#define MELLOW_H3R_D4 1
-#endif
 #define MELLOW_H3R(GV, DV)                                                                                                \
         do {                                                                                                              \
             const size_t lds = (size_t)36 * 3 * 64 * 16;                                                                  \

@@ -358,9 +358,13 @@ static int streams_overlap(mellow_engine* e, hipStream_t a, hipStream_t b, bool*
     return 0;
 }
 int ensure_prefill_streams(mellow_engine* e) {
-    if (e->streams_probed) return 0;
+    if (e->streams_probed) {          // a probe already found no free hardware queue: one chain, whatever set prefill_parts since
+        e->prefill_parts = 1;
+        return 0;
+    }
     int nh = e->prefill_parts < 1 ? 1 : (e->prefill_parts > 4 ? 4 : e->prefill_parts);
     for (int h = 1; h < nh; ++h) {
+        if (e->stream2[h - 1]) continue;          // created and measured by an earlier call
         bool ok = false;
         for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
             hipStream_t st = nullptr;
@@ -372,10 +376,10 @@ int ensure_prefill_streams(mellow_engine* e) {
         if (!ok) {                // this process's HIP runtime has no free hardware queue for us: one chain, and say so
             for (int k = 1; k < h; ++k) { hipStreamDestroy(e->stream2[k - 1]); e->stream2[k - 1] = nullptr; }
             e->prefill_parts = 1;
+            e->streams_probed = true;            // = "probed and serialising": never tried again
             break;
         }
     }
-    e->streams_probed = true;
     return 0;
 }
 extern "C" {

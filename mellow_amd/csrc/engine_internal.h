@@ -114,7 +114,7 @@ struct mellow_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     int prefill_parts = 2;                      // parts of the split LM prefill (MELLOW_PREFILL_SPLIT, read when the engine is created)
-    bool streams_probed = false;                // the side streams exist and were measured to overlap the main one (ensure_prefill_streams)
+    bool streams_probed = false;                // a probe found NO stream that overlaps the main one: the prefill stays one chain (ensure_prefill_streams)
     hipStream_t stream2[3] = {nullptr, nullptr, nullptr};      // further streams of the split LM prefill (run_prefill)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;

@@ -20,6 +20,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         CHK(ensure(e, e->lm_h3, Mq * 1536 * 6 / 4));
         CHK(ensure(e, e->lm_ssq, Mq * 2 * 16));        // two statistics per row (after o_proj / after down), 9 partial sums each
     }
+    dec_prepare_lds_attributes();            // (remembered per device: a no-op after the first call)
     const int Bp = rb_of(B) * 32;
     if (e->kv_B != Bp || e->kv_Tmax != Tmax) {
         e->kv_B = Bp;

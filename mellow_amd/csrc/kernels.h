@@ -191,6 +191,7 @@ void launch_kv_to_bf16(const float* src, void* dst, int64_t n, hipStream_t s);
 void launch_dec_qkv2(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
 // f32x3 forms for any number of row blocks (operands a.xmid3_32 / a.h3 / a.xmid3_16 pre-split by the o_proj / gate-up launches)
 void launch_dec_qkv2x3(const DecArgs& a, const float* Wq2, const float* Wd, hipStream_t s);
+void dec_prepare_lds_attributes();      // once per device, outside any stream capture: dynamic-LDS limits of the kernels above
 void launch_dec_gateup3(const DecArgs& a, const float* Wp16n_folded_pairs, hipStream_t s);
 // the same launch on e4m3 weights: the unfused layer's q/k/v copy (72 k-tiles per n-tile), the composed W' Wd (192) and the
 // down copy, one scale per packed row each (launch_pack_dec_fp8)
