@@ -301,6 +301,40 @@ def test_multi_row_block_batch(engine):
     assert np.array_equal(t40[:3], t_lo) and np.array_equal(t40[35:40], t_hi)
 
 
+def test_multi_row_block_decode_logits_match_the_one_block_path(engine, engine_f32):
+    """The decode step of a batch of more than 32 rows runs other kernels than one of up to 32 rows (f32x3 mode, round 5:
+    `dec_qkv2x3_kernel` / `dec_gateup3_kernel` serve every row block with weights split once, activations pre-split by their
+    producers, and the lm_head streams its weights once for all blocks; the reference's loop is batch-agnostic,
+    wrapper.py:216-249).  LOGITS, not only tokens: rows 0, 1 (block 0), 40 (block 1) and 94, 95 (block 2, ragged: B = 96 is three
+    blocks, 72 is two + a quarter) of a teacher-forced B = 96 / B = 72 run against the same examples run alone through the
+    one-block kernels, prefill + 4 decode steps: <= 1e-3 in the f32x3 mode (another summation order), 3e-3 against the exact
+    fp32 engine, arg-max equal."""
+    for B, pick in ((96, [0, 1, 40, 94, 95]), (72, [0, 33, 70, 71])):
+        a1, a2, ids = synth.make_batch(B)
+        pre_big = engine.prefix(a1, a2, ids)
+        sub = np.asarray(pick)
+        _close(pre_big[sub], engine.prefix(a1[sub], a2[sub], ids[sub]), rel=1e-5, name="prefix rows: only the split-K summation order depends on the batch")
+        pre_small = pre_big[torch.from_numpy(sub).to(pre_big.device)].clone()          # the LM sees the same rows either way
+        l_small = engine.lm_prefill(pre_small, reserve=8).clone()
+        l_f32 = engine_f32.lm_prefill(pre_small, reserve=8).clone()
+        small_steps, f32_steps, toks = [l_small], [l_f32], []
+        for i in range(4):
+            tok = small_steps[-1].argmax(-1)
+            toks.append(tok)
+            small_steps.append(engine.lm_decode_step(tok).clone())
+            f32_steps.append(engine_f32.lm_decode_step(tok).clone())
+        l_big = engine.lm_prefill(pre_big, reserve=8)
+        for i in range(5):
+            if i:
+                full = l_big.argmax(-1)                      # the other rows follow their own greedy tokens
+                full[torch.from_numpy(sub).to(full.device)] = toks[i - 1]
+                l_big = engine.lm_decode_step(full)
+            got = l_big[torch.from_numpy(sub).to(l_big.device)]
+            _close(got, small_steps[i], rel=0, atol=1e-3, name=f"B = {B}, step {i}: rows of the multi-block step vs the same rows alone")
+            _close(got, f32_steps[i], rel=0, atol=3e-3, name=f"B = {B}, step {i}: vs the exact fp32 engine")
+            assert torch.equal(got.argmax(-1), small_steps[i].argmax(-1))
+
+
 @pytest.fixture(scope="module")
 def batch1024():
     return synth.make_batch(1024)
