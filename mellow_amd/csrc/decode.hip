@@ -992,7 +992,7 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
 #endif
 constexpr int LM3_WAVES = MELLOW_LM3_WAVES;
 // K4x  lm_head, f32x3 form.  grid (n-tiles), LM3_WAVES waves x (72 / LM3_WAVES) k-tiles; loops over the row blocks.
-// (taps on caller-supplied rows; generation runs dec_head3_kernel below on activations the final norm pre-split)
+// (taps on caller-supplied rows; generation runs dec_head3r_kernel below on activations the final norm pre-split)
 template <bool BLK>
 __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
                                                                     int N, int RB_p, const DecArgs a) {
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
 // ----------------------------------------------------------------------------------------------------
 // K4y  lm_head, f32x3 form, as a streaming GEMM: one WAVE owns a 32-row n-tile over the WHOLE K = 576 (no split-K, no LDS
 //      reduction), a workgroup = H3_NW waves = H3_NW consecutive n-tiles, and the pre-split activations (F3-32, written by the
-//      final norm) of up to G row blocks go through LDS in K-chunks of H3_CP pairs, shared by the waves.  The weights are
+//      final norm) of up to G row blocks sit in LDS, shared by the waves.  The weights are
 //      streamed ONCE per step whatever the batch (the fp32 kernel above re-reads them per row block and every 32-row tile
 //      re-reads x: at B = 128 that is 4 x 113 MB of weights and 0.45 GB of activations through the L2s), split to bf16 triples
 //      in registers once per chunk and used for all G row blocks.  Rows beyond G blocks: further passes.
@@ -1095,9 +1095,6 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
 // ----------------------------------------------------------------------------------------------------
 #ifndef MELLOW_H3_NW
 #define MELLOW_H3_NW 8
-#endif
-#ifndef MELLOW_H3_RESIDENT
-#define MELLOW_H3_RESIDENT 1      // the lm_head with the activations resident in LDS (dec_head3r_kernel); 0 = the chunked stage (dec_head3_kernel)
 #endif
 #ifndef MELLOW_H3R_D1
 #define MELLOW_H3R_D1 1           // weight chunks in flight per wave at 1 / 2 / >= 3 row blocks (2 and 3 measured slower)
@@ -1108,129 +1105,11 @@ __global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float*
 #ifndef MELLOW_H3R_D4
 #define MELLOW_H3R_D4 1
 #endif
-#ifndef MELLOW_H3_D1
-#define MELLOW_H3_D1 1
-#endif
-#ifndef MELLOW_H3_D2
-#define MELLOW_H3_D2 1
-#endif
-#ifndef MELLOW_H3_D4
-#define MELLOW_H3_D4 1
-#endif
 constexpr int H3_NW = MELLOW_H3_NW, H3_CP = 3, H3_NC = 36 / H3_CP;
-// D = chunks of weights a wave keeps in flight ahead of the one it multiplies (registers): what hides the HBM latency behind the
-// matrix work of a chunk -- 0.24 us per row block, against 2-3 us of latency under load
-template <int G, int D, bool BLK>
-__global__ __launch_bounds__(H3_NW * 64) void dec_head3_kernel(const float* __restrict__ Wp, const i32x4* __restrict__ X3, int K8p, int N,
-                                                               int RB_p, const DecArgs a) {
-    kspan(a.dbg_seq, 0);
-    extern __shared__ __attribute__((aligned(16))) i32x4 xs[];        // [2 stages][G][H3_CP][3][64]
-    constexpr int STAGE = G * H3_CP * 3 * 64;                          // 16-byte slots per stage
-    constexpr int FILL = (STAGE + H3_NW * 64 - 1) / (H3_NW * 64);     // slots per thread per chunk
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x * H3_NW + wave;
-    const float4* wbase = reinterpret_cast<const float4*>(Wp) + (int64_t)nt * K8p * 64 + lane;
-    for (int rb0 = 0; rb0 < RB_p; rb0 += G) {
-        const int gn = min(G, RB_p - rb0);
-        f32x16 acc[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        // chunk c of x for the gn row blocks: slot i of the stage = (g, p, piece, lane) -> X3[((rb0 + g) * 36 + c * CP + p) * 3 + piece][lane]
-        auto x_src = [&](int c, int i) {
-            const int g = i / (H3_CP * 3 * 64), rest = i % (H3_CP * 3 * 64);
-            return X3 + (((int64_t)(rb0 + (g < gn ? g : 0)) * 36 + c * H3_CP) * 3) * 64 + rest;
-        };
-        float4 wn[D][2 * H3_CP];
-        i32x4 xf[FILL];
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + (d * 2 * H3_CP + i) * 64);
-#pragma unroll
-        for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) xs[i] = *x_src(0, i); }
-        static_assert(H3_NC % D == 0, "the chunk loop is unrolled by the prefetch depth");
-        for (int c0 = 0; c0 < H3_NC; c0 += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int c = c0 + d;
-                __syncthreads();              // stage c % 2 is complete; every read of stage (c + 1) % 2 (iteration c - 1) is done
-                float4 w[2 * H3_CP];
-#pragma unroll
-                for (int i = 0; i < 2 * H3_CP; ++i) w[i] = wn[d][i];
-                if (c + D < H3_NC) {
-#pragma unroll
-                    for (int i = 0; i < 2 * H3_CP; ++i) wn[d][i] = ldg_nt(wbase + ((c + D) * 2 * H3_CP + i) * 64);
-                }
-                if (c + 1 < H3_NC) {
-#pragma unroll
-                    for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) xf[j] = *x_src(c + 1, i); }
-                }
-                __builtin_amdgcn_sched_barrier(0);       // (keeps the next chunks' loads where they are: ahead of this chunk's work)
-                i32x4 wp[H3_CP][3];
-#pragma unroll
-                for (int p = 0; p < H3_CP; ++p) {
-                    pair_natural(w[2 * p], w[2 * p + 1]);
-                    split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
-                }
-                const i32x4* st = xs + (c & 1) * STAGE + lane;
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (g < gn) {
-#pragma unroll
-                        for (int p = 0; p < H3_CP; ++p) {
-                            const i32x4 xq[3] = {st[((g * H3_CP + p) * 3 + 0) * 64], st[((g * H3_CP + p) * 3 + 1) * 64], st[((g * H3_CP + p) * 3 + 2) * 64]};
-                            acc[g] = mma6(acc[g], wp[p], xq);
-                        }
-                    }
-                }
-                if (c + 1 < H3_NC) {
-                    i32x4* dst = xs + ((c + 1) & 1) * STAGE;
-#pragma unroll
-                    for (int j = 0; j < FILL; ++j) { const int i = tid + j * H3_NW * 64; if (i < STAGE) dst[i] = xf[j]; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // epilogue: D[n = 8 (r / 4) + 4 h + r % 4][m = lane % 32], h = lane / 32
-        const int m = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g < gn && !(BLK && a.blk_live[rb0 + g] == 0)) {
-                const int64_t row = (int64_t)(rb0 + g) * 32 + m;
-                float bv = -INFINITY;
-                int bi = 0x7fffffff;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nt * 32 + 8 * q + 4 * h;
-                    if (a.logits) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (arg_better(acc[g][4 * q + j], n + j, bv, bi)) { bv = acc[g][4 * q + j]; bi = n + j; }
-                }
-                // the other half-wave holds the row's other 16 columns
-                auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
-                auto ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
-                const float ov = __uint_as_float(h ? rv[0] : rv[1]);
-                const int oi = (int)(h ? ri[0] : ri[1]);
-                if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-                if (h == 0) {
-                    const int64_t o = row * (N >> 5) + nt;
-                    a.cand_val[o] = bv;
-                    a.cand_idx[o] = bi;
-                }
-            }
-        }
-        if (rb0 + G < RB_p) __syncthreads();          // the next pass refills stage 0
-    }
-    kspan(a.dbg_seq, 1);
-}
-
-// K4z  the same streaming lm_head with the activations RESIDENT in LDS: the G row blocks' fragments of 36 / G k-pairs fill the
-//      108 KiB stage once per phase (G phases), and inside a phase the waves run without any barrier -- each streams its own
-//      n-tile's weights D chunks ahead and reads the fragments it needs from LDS.  (K4y refills a small stage every chunk: one
-//      barrier + one L2 round trip per chunk, 12 per row-block pass, which is what bounds it at one row block.)
+//      Activations RESIDENT in LDS: the G row blocks' fragments of 36 / G k-pairs fill the 108 KiB stage once per phase (G
+//      phases), and inside a phase the waves run without any barrier -- each streams its own n-tile's weights D chunks ahead
+//      (D = 1: deeper register prefetch measured slower) and reads the fragments it needs from LDS.  (A first form refilled a small
+//      stage every chunk -- one barrier + one L2 round trip per chunk: tools/experiments/r05_dec_head3_kernel.hip.txt.)
 template <int G, int D, bool BLK>
 __global__ __launch_bounds__(H3_NW * 64) void dec_head3r_kernel(const float* __restrict__ Wp, const i32x4* __restrict__ X3, int K8p, int N,
                                                                 int RB_p, const DecArgs a) {
@@ -2381,14 +2260,6 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
         // f32x3 mode, activations pre-split by the final norm: the streaming form (weights read once for every row block)
         const dim3 grid(vocab / 32 / H3_NW), block(H3_NW * 64);
         const i32x4* X3 = reinterpret_cast<const i32x4*>(a.xn3);
-#define MELLOW_H3(GV, DV)                                                                                                 \
-        do {                                                                                                              \
-            const size_t lds = (size_t)2 * GV * H3_CP * 3 * 64 * 16;                                                      \
-            if (a.blk_live) { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, true>), lds);           \
-                              hipLaunchKernelGGL((dec_head3_kernel<GV, DV, true>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
-            else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3_kernel<GV, DV, false>), lds);                      \
-                   hipLaunchKernelGGL((dec_head3_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
-        } while (0)
 #define MELLOW_H3R(GV, DV)                                                                                                \
         do {                                                                                                              \
             const size_t lds = (size_t)36 * 3 * 64 * 16;                                                                  \
@@ -2397,12 +2268,8 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
             else { set_max_dynamic_lds(reinterpret_cast<const void*>(&dec_head3r_kernel<GV, DV, false>), lds);             \
                    hipLaunchKernelGGL((dec_head3r_kernel<GV, DV, false>), grid, block, lds, s, Wp, X3, K8p, vocab, a.RB, a); } \
         } while (0)
-        if (MELLOW_H3_RESIDENT) {
-            if (a.RB == 1) MELLOW_H3R(1, MELLOW_H3R_D1); else if (a.RB == 2) MELLOW_H3R(2, MELLOW_H3R_D2); else MELLOW_H3R(4, MELLOW_H3R_D4);
-        } else
-        if (a.RB == 1) MELLOW_H3(1, MELLOW_H3_D1); else if (a.RB == 2) MELLOW_H3(2, MELLOW_H3_D2); else MELLOW_H3(4, MELLOW_H3_D4);
+        if (a.RB == 1) MELLOW_H3R(1, MELLOW_H3R_D1); else if (a.RB == 2) MELLOW_H3R(2, MELLOW_H3R_D2); else MELLOW_H3R(4, MELLOW_H3R_D4);
 #undef MELLOW_H3R
-#undef MELLOW_H3
         return;
     }
     if ((a.x3 & DEC_X3_HEAD) && !wscale) {          // f32x3 mode on caller rows (taps): operands split in registers
