@@ -73,6 +73,8 @@ struct GemmBDev {
     GemmArgs a;
     int gm, gn;
     int ks;                 // split-K: workgroups per output tile (1 = none); tile = L % (gm gn), split = L / (gm gn)
+    int ng = 0;             // x3q, wide outputs (gn % 8 == 0, gn >= 16, no split-K): XCD x owns the n-tiles [x gn/8, (x+1) gn/8) for EVERY row
+                            // panel -- its gn/8 weight tiles stay in its 4 MiB L2 while the panels stream through (below)
 };
 
 // Split-K for launches that would leave most of the chip idle (<= 256 output tiles: the tail GEMMs of the encoder).  Two
@@ -517,9 +519,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x3q_kernel(const GemmBDev p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles = p.gm * p.gn;
-    const int L = xcd_remap((int)blockIdx.x, tiles * p.ks);
-    const int tile = L % tiles, split = L / tiles;
-    const int pm = tile / p.gn, pn = tile % p.gn;
+    int tile, split, pm, pn;
+    if (p.ng) {
+        // Weight-stationary per XCD (block b runs on XCD b % 8: observed, speed only).  With the panel-major order below, an XCD
+        // walks ~12 row panels and needs ALL gn weight tiles for each: the LM's gate/up operand is 10.6 MB against a 4 MiB L2, so
+        // every panel re-fetched the whole weight -- measured 850 MB of reads per launch for 54 MB of operands, 45 % of the
+        // family's memory-side traffic, and the launch ran at the fabric's rate (profiles/r05_pmc_traffic_by_shape_*.txt).  Here an
+        // XCD keeps gn / 8 weight tiles (1.3 MB) hot and every panel is read once per XCD: 8 x 43 + 10.6 MB.
+        const int npx = p.gn >> 3, b = (int)blockIdx.x, j = b >> 3;
+        pm = j / npx; pn = (b & 7) * npx + j % npx;
+        tile = pm * p.gn + pn; split = 0;
+    } else {
+        const int L = xcd_remap((int)blockIdx.x, tiles * p.ks);
+        tile = L % tiles; split = L / tiles;
+        pm = tile / p.gn; pn = tile % p.gn;
+    }
     const int KTf = g.K >> 4;
     const int kt0 = split * KTf / p.ks;
     const int KT = (split + 1) * KTf / p.ks - kt0;                          // this workgroup's k16 steps (split-K, see splitk_store)
@@ -862,6 +876,8 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
     d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
+    static const bool no_ng = getenv("MELLOW_X3Q_NGROUP") && getenv("MELLOW_X3Q_NGROUP")[0] == '0';      // developer A/B
+    d.ng = (!no_ng && d.ks == 1 && d.gn % 8 == 0 && d.gn >= 16) ? 1 : 0;
     const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                              // 72 KiB
     set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), lds);
     hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
