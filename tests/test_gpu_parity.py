@@ -886,6 +886,30 @@ def test_config3_shape_max_len_300_sampling_args(engine, golden_dir):
     assert int(lens[0]) == k and n >= k + 1 and np.array_equal(ts[0, : k + 1], row[: k + 1])
 
 
+def test_f32_and_f32x3_agree_over_the_300_step_run(engine_f32, synth_sd, golden_dir):
+    """The two precision modes against EACH OTHER on BASELINE configs[2]'s per-rank run (32 rows x 300 steps): every row that
+    stays on the reference (31 of 32, see the departures table above) is token-identical between the modes for all 300 steps,
+    and row 10 -- which both modes take off the reference at its 8.4e-5 near-tie of step 153 -- is identical up to there; after
+    it the two modes may follow different sequences (they are different fp32 summation orders on a sequence the reference never
+    produced), which is reported, not asserted."""
+    from mellow_amd.engine import Engine
+    e3 = Engine(device=0, precision="f32x3")
+    e3.load_state_dict(synth_sd)
+    a1, a2, ids = synth.make_batch(32)
+    t0, *_ = engine_f32.generate(a1, a2, ids, max_len=300, stop_id=0, ignore_stop=True)
+    t3, *_ = e3.generate(a1, a2, ids, max_len=300, stop_id=0, ignore_stop=True)
+    e3.close()
+    gl = np.load(os.path.join(golden_dir, "b32long.npz"))
+    for r in range(32):
+        d = np.flatnonzero(t0[r] != t3[r])
+        if r == 10:
+            assert d.size == 0 or int(d[0]) >= 153, (r, d[:4])
+            print("row 10 after its departure from the reference: the modes", "agree" if d.size == 0 else f"part at step {int(d[0])}")
+        else:
+            assert d.size == 0, (r, int(d[0]))
+            assert np.array_equal(t0[r], gl["tokens"][r])
+
+
 def test_config4_shape_30s_clips_max_len_128(engine, golden_dir):
     """BASELINE configs[3] at its full size: batch 64, 2 x 30 s clips (7 encoder crops per clip = 896 crops), max_len=128.
     Rows 0 and 1 are pinned to the REFERENCE itself (tests/golden/cfg3.npz: the imported reference's `generate_prefix_inference`
