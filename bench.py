@@ -300,7 +300,7 @@ def alt_modes(B: int, L: int, headline: str):
                 e.generate(b1d, b2d, bid, max_len=L, stop_id=0, ignore_stop=True)
             torch.cuda.synchronize()
             ph8 = e.last_phase_ms()
-            kv16 = os.environ.get("MELLOW_FP8_KV16", "1") != "0"
+            kv16 = bool(e.describe()["options"]["fp8_kv16"]["value"])
             b8 = decode_algorithmic_bytes_fp8(128, L) if kv16 else (decode_algorithmic_bytes(128, L) - (L - 1) * 134_515_008 * 3.0)
             res["fp8_b128"] = {"batch": 128, "value": round(2 * 128 / (time.perf_counter() - t0), 2), "unit": "responses/s",
                                "phase_ms": {k: round(v, 2) for k, v in ph8.items()},
@@ -361,19 +361,33 @@ def main():
     ap.add_argument("--inflight", type=int, default=4,
                     help="also measure N engine contexts (one weight copy, mellow_engine_fork) pipelining independent batches on this "
                          "GPU: the supplementary 'pipelined' object, never the headline value; 0 or 1 skips it")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine option (mellow_engine_set_option; repeatable): a non-default configuration is printed in the line's "
+                         "`engine` object and the line says so -- the library itself reads no environment variable")
     args = ap.parse_args()
+    try:
+        engine_options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1], 0) for kv in args.option}
+    except (IndexError, ValueError):
+        ap.error("--option wants KEY=INTEGER")
     if args.preset == "configs2":
         args.batch, args.max_len = 32, 300
     elif args.preset == "configs3":
         args.batch, args.max_len, args.clip_seconds = 64, 128, 30
     elif args.preset == "configs4":
         args.batch, args.max_len, args.precision = 128, 64, "fp8"
-    # every MELLOW_* variable this process saw goes into the line; developer probes that change the answers (MELLOW_DEV_*,
-    # honoured only by -DMELLOW_DEVPROBE builds) are refused outright: a number measured under one is not a measurement
+    # The release library reads no environment variable (round 6: every switch is an engine option, reported by
+    # mellow_engine_describe and printed below as `engine`).  What the process environment can still influence is listed in the
+    # line: the binding's / this script's own MELLOW_* variables and the HIP runtime's queue count.  Developer probes (MELLOW_DEV_*,
+    # honoured only by -DMELLOW_DEVPROBE builds) and the library switches of earlier rounds are refused outright: a number
+    # measured under a probe is not a measurement, and a stale switch means the caller expects a configuration it is not getting.
+    HARNESS_ENV = {"MELLOW_HIP_LIB", "MELLOW_PRECISION", "MELLOW_BENCH_BACKEND", "MELLOW_BENCH_DEVICE", "MELLOW_BENCH_FORCE_DIST",
+                   "MELLOW_DP_AGREE_TIMEOUT_S", "MELLOW_HWQ_SET_BY_IMPORT", "MELLOW_CKPT_DIR", "MELLOW_TOKENIZER_DIR", "MELLOW_DATA_PARALLEL",
+                   "MELLOW_DEVICE_RESAMPLE"}
     mellow_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MELLOW_") or k == "GPU_MAX_HW_QUEUES"}
-    bad = [k for k in mellow_env if k.startswith("MELLOW_DEV_")]
+    bad = [k for k in mellow_env if k.startswith("MELLOW_") and k not in HARNESS_ENV]
     if bad:
-        print(f"bench.py: refusing to run with developer probes set: {bad}", file=sys.stderr)
+        print(f"bench.py: refusing to run with {bad} set: the library ignores environment variables; use --option KEY=VALUE "
+              f"(engine options) instead", file=sys.stderr)
         sys.exit(2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -403,7 +417,7 @@ def main():
     from mellow_amd import synth, dist as mdist
     from mellow_amd.engine import Engine
     dev = local_rank if use_dist else 0
-    eng = Engine(device=dev, precision=args.precision)     # raises if libmellow_hip.so or the GPU is missing
+    eng = Engine(device=dev, precision=args.precision, options=engine_options)     # raises if libmellow_hip.so or the GPU is missing
     eng.load_state_dict(synth.make_state_dict(0))
     comm_dev = eng.tdev if backend == "nccl" else torch.device("cpu")      # where the collectives' buffers live
     B, L = args.batch, args.max_len
@@ -497,7 +511,7 @@ def main():
         if args.precision == "fp8":
             # the fp8 mode is priced on ITS OWN bytes (e4m3 weights 134.5 MB per step; K/V as the mode stores them):
             # pricing it on the fp32 mode's 538 MB + 46,080 B per token would flatter it
-            kv16 = os.environ.get("MELLOW_FP8_KV16", "1") != "0"
+            kv16 = bool(eng.describe()["options"]["fp8_kv16"]["value"])
             dec_bytes = decode_algorithmic_bytes_fp8(B, L) if kv16 else decode_algorithmic_bytes(B, L) - (L - 1) * 134_515_008 * 3.0
         dec_gbs = dec_bytes / (phases["decode_ms"] * 1e-3) / 1e9 if phases["decode_ms"] > 0 else 0.0
         # whole-path two-phase roofline: t_roof = F_dense/P_mfma + Bytes_decode/BW_hbm
@@ -527,6 +541,7 @@ def main():
                            "precision modes and continues on another sequence (147 tokens); the other 31 rows are equal for all 300 steps; 9 "
                            "of the 9,600 reference decisions have a gap < 6e-3 (counted in tests/test_oracle_golden.py)",
             "env": mellow_env,
+            "engine": eng.describe(),                  # the library's resolved configuration (mellow_engine_describe); non_default == [] in the driver's run
             "prefill_parts": eng.prefill_parts(),      # measured by the engine: 2 = two half-batch chains on streams that overlap
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
@@ -566,7 +581,7 @@ def main():
             "bytes_per_launch": round(dec_bytes / max(1, L - 1)),
             "share_of_pass": round(phases["decode_ms"] / ms_per_step, 3),
             "note": ("achieved = algorithmic bytes per step OF THE fp8 MODE (134.5 MB of e4m3 weights + 23,040 B of bf16 shadow pages per cached token "
-                     "per example; fp32 pages with MELLOW_FP8_KV16=0) " if args.precision == "fp8" else
+                     "per example; fp32 pages with --option fp8_kv16=0) " if args.precision == "fp8" else
                      "achieved = algorithmic bytes per step (538.06 MB of fp32 weights + 46,080 B per cached token per example, SURVEY 8d) ") +
                     "/ average step time, HIP events around the decode phase of the timed pass on the engine's stream",
         }

@@ -41,8 +41,11 @@ extern "C" {
  *     (split-K for small launches; from round 5 the decode step of a batch of more than 32 rows runs other kernels than one of
  *     up to 32 rows): greedy tokens are asserted equal across those forms on the reference's fixtures, logits agree to 1e-3;
  *     a caller that needs bit-identical, batch-size-independent GEMMs selects MELLOW_PRECISION_F32.
- *  2: mellow_prefill_parts (round 5). */
-#define MELLOW_ABI_MINOR 2
+ *  2: mellow_prefill_parts (round 5).
+ *  3: mellow_engine_set_option / mellow_engine_describe (round 6): the library no longer reads ANY environment variable; every
+ *     switch it has is a named option, and the resolved configuration can be printed.  mellow_debug_gemm_f32 modes 6 / 9 are gone
+ *     (the pre-split debug kernel was removed; 16 / 17 are the engine's own f32x3 kernels). */
+#define MELLOW_ABI_MINOR 3
 
 typedef struct mellow_engine mellow_engine_t;
 
@@ -244,11 +247,26 @@ int         mellow_set_graph(mellow_engine_t* e, int on);
  *     fp32 MFMA kernel's), not bit-identical to MELLOW_PRECISION_F32.  Every engine-level parity test (tolerances against the
  *     reference's fp32 outputs, exact greedy tokens) runs in this mode and in MELLOW_PRECISION_F32.  In this mode the last bits
  *     of an example's activations may depend on how many examples the call holds: encoder launches of few output tiles are split
- *     along K (a fixed summation order per launch shape; MELLOW_SPLITK=0 in the environment turns it off). */
+ *     along K (a fixed summation order per launch shape; option "splitk" = 0 turns it off). */
 #define MELLOW_PRECISION_F32 0
 #define MELLOW_PRECISION_FP8 1
 #define MELLOW_PRECISION_F32X3 2
 int         mellow_engine_set_precision(mellow_engine_t* e, int mode);
+
+/* ---- explicit configuration (round 6).  The library reads no environment variable: a consumer's environment cannot change its
+ *      arithmetic.  Every switch is a named integer option, set after mellow_engine_create and before mellow_engine_finalize
+ *      ("arena_mb": before the first mellow_engine_load_tensor); an unknown key or a malformed value is an error.  The defaults
+ *      are the configuration bench.py measures and the parity suite runs; the reference has no counterpart (wrapper.py:35-49 has
+ *      no hidden modes, and neither has a default engine).  Keys: prefill_split, prefill_fuse_norm, decode_fuse,
+ *      decode_fuse_max_rb, splitk, enc_apb, graph, fp8_decode, fp8_prefill, fp8_decode_act, fp8_kv16, decode_x3, decode_x3_min_rb,
+ *      x3_stft, stft_fft, x3_apb, x3_attn, x3w, row_migration, arena_mb (mellow_amd/csrc/engine.cpp: kOptions says what each does
+ *      and whether it can change the answers). */
+int         mellow_engine_set_option(mellow_engine_t* e, const char* key, const char* value);
+/* JSON text: {"abi": [major, minor], "precision": "f32x3" | "f32" | "fp8", "reads_environment": false, "finalized": ...,
+ *  "stft_is_fft": ..., "non_default": [keys], "options": {key: {"value", "default", "changes_answers"}}}.  Returns the bytes the
+ *  text needs including its terminator (-1 for a null engine); writes it only when `capacity` suffices (call with buf = NULL
+ *  to size). */
+int64_t     mellow_engine_describe(mellow_engine_t* e, char* buf, int64_t capacity);
 
 /* ---- host-only helpers (callable without a GPU; used by CPU tests) -------------------------------- */
 /* token permutation of a Swin block: out[m] = source token (h*R+w) feeding window-order row m, for

@@ -987,102 +987,6 @@ __global__ __launch_bounds__(LM_WAVES * 64) void dec_fullk_kernel(const float* _
     kspan(a.dbg_seq, 1);
 }
 
-#ifndef MELLOW_LM3_WAVES
-#define MELLOW_LM3_WAVES 12
-#endif
-constexpr int LM3_WAVES = MELLOW_LM3_WAVES;
-// K4x  lm_head, f32x3 form.  grid (n-tiles), LM3_WAVES waves x (72 / LM3_WAVES) k-tiles; loops over the row blocks.
-// (taps on caller-supplied rows; generation runs dec_head3r_kernel below on activations the final norm pre-split)
-template <bool BLK>
-__global__ __launch_bounds__(LM3_WAVES * 64) void dec_fullk3_kernel(const float* __restrict__ Wp, const float* __restrict__ XF, int K8p,
-                                                                    int N, int RB_p, const DecArgs a) {
-    kspan(a.dbg_seq, 0);
-    __shared__ __attribute__((aligned(16))) float red[LM3_WAVES * 16 * 64];
-    constexpr int KPW = 72 / LM3_WAVES, PP = KPW / 2;
-    static_assert(KPW * LM3_WAVES == 72 && PP * 2 == KPW, "waves must divide the 72 k-tiles into whole pairs");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x;
-    const int k8_0 = wave * KPW;
-    const int64_t wslot = ((int64_t)nt * K8p + k8_0) * 64 + lane;
-    float4 w[KPW], x[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) w[i] = ldg_nt(reinterpret_cast<const float4*>(Wp) + wslot + i * 64);
-    int rb = 0;
-    if (BLK) { while (rb < RB_p && a.blk_live[rb] == 0) ++rb; }          // first live block (workgroup-uniform)
-    if (rb >= RB_p) return;
-    i32x4 xq[PP][3];
-    {
-        const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)rb * 72 + k8_0) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    i32x4 wp[PP][3];
-#pragma unroll
-    for (int p = 0; p < PP; ++p) split_pair(w[2 * p], w[2 * p + 1], wp[p][0], wp[p][1], wp[p][2]);
-    while (rb < RB_p) {
-        // (both operands are fp32 fragments of the same two k-tiles: lane half h holds k = 8 t + 4 h + j of either tile on both sides)
-#pragma unroll
-        for (int p = 0; p < PP; ++p) split_pair(x[2 * p], x[2 * p + 1], xq[p][0], xq[p][1], xq[p][2]);
-        int nrb = rb + 1;
-        if (BLK) { while (nrb < RB_p && a.blk_live[nrb] == 0) ++nrb; }
-        if (nrb < RB_p) {                   // the next block's fragments travel while this one is multiplied
-            const float4* xp = reinterpret_cast<const float4*>(XF) + ((int64_t)nrb * 72 + k8_0) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < KPW; ++i) x[i] = xp[i * 64];
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int p = 0; p < PP; ++p) acc = mma6(acc, wp[p], xq[p]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-        __syncthreads();
-        const bool epi = tid < 256;
-        const int mm = tid & 31, hh = (tid >> 5) & 1, gq = (tid >> 6) & 3;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 4 * gq + j;
-            float sacc = red[r * 64 + mm + 32 * hh];
-#pragma unroll
-            for (int wv = 1; wv < LM3_WAVES; ++wv) sacc += red[(wv * 16 + r) * 64 + mm + 32 * hh];      // fixed order
-            v[j] = sacc;
-        }
-        const int n = nt * 32 + 8 * gq + 4 * hh;
-        const int64_t row = (int64_t)rb * 32 + mm;
-        if (epi && a.logits && n < N) *reinterpret_cast<float4*>(a.logits + row * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-        // best (value, lowest index) of this 32-column tile per row (torch.argmax tie rule)
-        __syncthreads();
-        float bv = v[0];
-        int bi = n;
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-            if (arg_better(v[j], n + j, bv, bi)) { bv = v[j]; bi = n + j; }
-        if (epi) {
-            red[tid] = bv;
-            reinterpret_cast<int*>(red)[256 + tid] = bi;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            float best = red[tid];
-            int idx = reinterpret_cast<int*>(red)[256 + tid];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) {
-                const float ov = red[tid + 32 * q];
-                const int oi = reinterpret_cast<int*>(red)[256 + tid + 32 * q];
-                if (arg_better(ov, oi, best, idx)) { best = ov; idx = oi; }
-            }
-            const int64_t o = ((int64_t)rb * 32 + tid) * (N >> 5) + nt;
-            a.cand_val[o] = best;
-            a.cand_idx[o] = idx;
-        }
-        if (nrb < RB_p) __syncthreads();          // the next block's partial sums reuse `red`
-        rb = nrb;
-    }
-    kspan(a.dbg_seq, 1);
-}
 
 // ----------------------------------------------------------------------------------------------------
 // K4y  lm_head, f32x3 form, as a streaming GEMM: one WAVE owns a 32-row n-tile over the WHOLE K = 576 (no split-K, no LDS
@@ -2255,6 +2159,9 @@ void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipSt
         else hipLaunchKernelGGL((dec_final_norm_kernel<DEC_KC_DOWN, false>), dim3(a.rows), dim3(192), 0, s, norm_w, (const float*)a.xmidF, (const float*)a.dslabF, a.slabF_stride4, a);
     }
 }
+// true when the streaming f32x3 lm_head (dec_head3r_kernel) tiles this vocabulary: only then may the final norm hand its output
+// over pre-split (DecArgs::xn3, which aliases xnF) -- engine_lm.cpp: ensure_lm
+bool dec_head3r_fits(int vocab) { return vocab % 32 == 0 && (vocab / 32) % H3_NW == 0; }
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale) {
     if ((a.x3 & DEC_X3_HEAD) && !wscale && a.xn3 && (vocab / 32) % H3_NW == 0) {
         // f32x3 mode, activations pre-split by the final norm: the streaming form (weights read once for every row block)
@@ -2272,12 +2179,7 @@ void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, h
 #undef MELLOW_H3R
         return;
     }
-    if ((a.x3 & DEC_X3_HEAD) && !wscale) {          // f32x3 mode on caller rows (taps): operands split in registers
-        const dim3 grid(vocab / 32), block(LM3_WAVES * 64);
-        if (a.blk_live) hipLaunchKernelGGL((dec_fullk3_kernel<true>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
-        else hipLaunchKernelGGL((dec_fullk3_kernel<false>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a.RB, a);
-        return;
-    }
+    // (fp32 rows in xnF -- taps on caller rows, or a vocabulary the streaming form does not tile: the exact fp32 kernel below)
     const dim3 grid(vocab / 32, 1, a.RB), block(LM_WAVES * 64);
     const int mode = w8_mode(a, wscale);
     if (a.blk_live && mode == 2) hipLaunchKernelGGL((dec_fullk_kernel<OUT_LOGITS, true, 2>), grid, block, 0, s, Wp, (const float*)a.xnF, K8p, vocab, a, wscale);

@@ -410,74 +410,8 @@ void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, f
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, out, (int64_t)M, C, w, eps);
 }
 
-// ---- A7 window attention core: one wave per (window, head), lane = query token -------------------------------
-// reference htsat.py:301-327.  Inputs arrive in window order (the LN kernel did roll + partition), so a
-// window is 64 consecutive rows.  q/k/v of one head are 64x24: K and V sit in LDS (6 KiB each) and are
-// read as broadcasts; the lane keeps its 64 scores, softmax is entirely in-lane.
-__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                               int C, int nH, const float* __restrict__ bias_exp,
-                                                               const float* __restrict__ mask, int nW,
-                                                               int64_t n_tiles) {
-    __shared__ __attribute__((aligned(16))) float Ks[4][64 * 24];
-    __shared__ __attribute__((aligned(16))) float Vs[4][64 * 24];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;   // tile = window * nH + head
-    const bool active = tile < n_tiles;
-    const int64_t win = active ? tile / nH : 0;
-    const int hd = active ? (int)(tile % nH) : 0;
-    const float* row = qkv + (win * 64 + lane) * (3 * C) + hd * 24;
-    float q[24];
-    {
-        const float scale = 0.20412414523193150818f;  // 24^-0.5 (python float -> fp32 scalar multiply)
-#pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            const float4 t = *reinterpret_cast<const float4*>(row + v * 4);
-            q[4 * v] = t.x * scale; q[4 * v + 1] = t.y * scale; q[4 * v + 2] = t.z * scale; q[4 * v + 3] = t.w * scale;
-            *reinterpret_cast<float4*>(&Ks[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(row + C + v * 4);
-            *reinterpret_cast<float4*>(&Vs[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(row + 2 * C + v * 4);
-        }
-    }
-    __syncthreads();
-    float s[64];
-    const float* brow = bias_exp + ((int64_t)hd * 64 + lane) * 64;
-    const float* mrow = mask ? mask + ((win % nW) * 64 + lane) * 64 : nullptr;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float* kj = &Ks[wave][j * 24];
-        float a = 0.f;
-#pragma unroll
-        for (int d = 0; d < 24; ++d) a = fmaf(q[d], kj[d], a);
-        a = a + brow[j];
-        if (mrow) a = a + mrow[j];
-        s[j] = a;
-        mx = fmaxf(mx, a);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        s[j] = __builtin_amdgcn_exp2f((s[j] - mx) * 1.44269504088896340736f);   // hardware exp2: ~1e-6 relative on weights <= 1
-        sum += s[j];
-    }
-    const float inv = 1.0f / sum;
-    float o[24];
-#pragma unroll
-    for (int d = 0; d < 24; ++d) o[d] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float p = s[j] * inv;
-        const float* vj = &Vs[wave][j * 24];
-#pragma unroll
-        for (int d = 0; d < 24; ++d) o[d] = fmaf(p, vj[d], o[d]);
-    }
-    if (active) {
-        float* dst = out + (win * 64 + lane) * C + hd * 24;
-#pragma unroll
-        for (int v = 0; v < 6; ++v)
-            *reinterpret_cast<float4*>(dst + v * 4) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
-    }
-}
-// ---- the same on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32) -------------------------------------------------
+// ---- A7 window attention core on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32); reference htsat.py:301-327.  Inputs arrive in
+// window order (the LN kernel did roll + partition), so a window is 64 consecutive rows. ----------------------------------------
 // One wave per (window, head).  Scores are computed TRANSPOSED, S^T[key][query] = sum_d K[key][d] Q[query][d] (K tile = MFMA A
 // operand, Q = B operand), so a lane owns ONE query column and 16 keys of each 32-key tile: the softmax over the 64 keys of a
 // query is in-lane plus one half-wave exchange, and the P^T accumulator registers are directly the B operand of
@@ -622,13 +556,8 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float*
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
                              const float* mask, int nW, hipStream_t s, void* out_apb) {
     const int64_t n_tiles = (int64_t)(M / 64) * nH;
-    static const bool valu = getenv("MELLOW_WINATTN_VALU") != nullptr;     // developer A/B: the VALU kernel above
-    if (valu && !out_apb)
-        hipLaunchKernelGGL(window_attention_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
-                           bias_exp, mask, nW, n_tiles);
-    else
-        hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
-                           bias_exp, mask, nW, n_tiles, reinterpret_cast<i32x4*>(out_apb));
+    hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+                       bias_exp, mask, nW, n_tiles, reinterpret_cast<i32x4*>(out_apb));
 }
 
 // ---- A10 tail: latent mean + im2col for the token-semantic conv (htsat.py:742-775) ---------------------------

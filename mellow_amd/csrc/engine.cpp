@@ -33,9 +33,7 @@ int ensure(mellow_engine* e, mellow_engine::Buf& b, size_t floats) {
 int dev_alloc(mellow_engine* e, float** out, size_t floats) {
     const size_t bytes = (floats * sizeof(float) + 4095) / 4096 * 4096;
     if (!e->arena) {
-        size_t want = (size_t)3400 << 20;
-        const char* env = getenv("MELLOW_ARENA_MB");
-        if (env) want = (size_t)atol(env) << 20;
+        const size_t want = (size_t)(e->arena_mb < 0 ? 0 : e->arena_mb) << 20;        // option "arena_mb" (default 3400)
         if (want) {
             void* p = nullptr;
             if (hipMalloc(&p, want) == hipSuccess) {
@@ -239,16 +237,9 @@ int mellow_engine_create(const mellow_config_t* cfg, int device, mellow_engine_t
     e->cfg = *cfg;
     e->device = device;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    if (const char* pp = getenv("MELLOW_PREFILL_SPLIT")) e->prefill_parts = atoi(pp);
-    if (const char* fn = getenv("MELLOW_PREFILL_FUSE_NORM")) e->prefill_fuse_norm = fn[0] != '0';
-    if (const char* fr = getenv("MELLOW_DECODE_FUSE_MAX_RB")) e->dec_fuse_max_rb = atoi(fr);
-    if (const char* sk = getenv("MELLOW_SPLITK")) e->sk_max = atoi(sk);
-    if (const char* ea = getenv("MELLOW_ENC_APB")) e->enc_apb_stages = (int)strtol(ea, nullptr, 0);
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));      // (streams: on first use)
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&e->ev_phase[i]));
-    const char* ng = getenv("MELLOW_NO_GRAPH");
-    if (ng && ng[0] == '1') e->use_graph = false;
     *out = e;
     // the default numeric mode (include/mellow_hip.h): fp32-accurate GEMMs on the bf16 matrix pipe -- the mode bench.py measures
     // and every engine-level parity test runs (next to the exact-fp32 MFMA mode); mellow_engine_set_precision overrides it
@@ -358,9 +349,14 @@ static int streams_overlap(mellow_engine* e, hipStream_t a, hipStream_t b, bool*
     return 0;
 }
 int ensure_prefill_streams(mellow_engine* e) {
-    if (e->streams_probed) {          // a probe already found no free hardware queue: one chain, whatever set prefill_parts since
-        e->prefill_parts = 1;
-        return 0;
+    // A failed probe is not final: another process (or a profiler) may have kept the queues busy during the 200 us window.  The
+    // engine stays on what it has for the next 16 calls, then probes again; streams that passed are kept.
+    if (e->n_forks > 0 || e->parent) return 0;       // pipelined contexts do not split (mellow_engine_fork)
+    if (e->streams_probed) {
+        if (++e->probe_backoff < 16) { e->prefill_parts = e->prefill_parts_ok; return 0; }
+        e->streams_probed = false;
+        e->probe_backoff = 0;
+        e->prefill_parts = e->prefill_parts_want;
     }
     int nh = e->prefill_parts < 1 ? 1 : (e->prefill_parts > 4 ? 4 : e->prefill_parts);
     for (int h = 1; h < nh; ++h) {
@@ -369,20 +365,130 @@ int ensure_prefill_streams(mellow_engine* e) {
         for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
             hipStream_t st = nullptr;
             HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            CHK(streams_overlap(e, e->stream, st, &ok));
-            for (int k = 1; k < h && ok; ++k) CHK(streams_overlap(e, e->stream2[k - 1], st, &ok));
+            int rc = streams_overlap(e, e->stream, st, &ok);
+            for (int k = 1; k < h && ok && !rc; ++k) rc = streams_overlap(e, e->stream2[k - 1], st, &ok);
+            if (rc) { hipStreamDestroy(st); return rc; }
             if (ok) e->stream2[h - 1] = st; else hipStreamDestroy(st);
         }
-        if (!ok) {                // this process's HIP runtime has no free hardware queue for us: one chain, and say so
-            for (int k = 1; k < h; ++k) { hipStreamDestroy(e->stream2[k - 1]); e->stream2[k - 1] = nullptr; }
-            e->prefill_parts = 1;
-            e->streams_probed = true;            // = "probed and serialising": never tried again
+        if (!ok) {                // no further free hardware queue right now: run on the h streams that passed, and say so
+            e->prefill_parts_want = e->prefill_parts;
+            e->prefill_parts = e->prefill_parts_ok = h;
+            e->streams_probed = true;            // = "probed and short of queues": tried again after 16 calls
             break;
         }
     }
     return 0;
 }
+// ---- explicit configuration --------------------------------------------------------------------------------------------------
+// Every switch of the library is a named option set through mellow_engine_set_option (before mellow_engine_finalize) and reported
+// by mellow_engine_describe: the library reads no environment variable, so a C-ABI consumer's environment cannot change its
+// arithmetic.  "answers" marks the options that may change last bits or the numeric mode; the others select between forms that
+// are bit-identical (asserted in tests/test_gpu_parity.py) or change scheduling only.
+struct OptDesc { const char* key; const char* dflt; bool answers; const char* what; };
+static const OptDesc kOptions[] = {
+    {"prefill_split", "2", false, "f32x3: parts of the split LM prefill (1..4); bit-identical for every value"},
+    {"prefill_fuse_norm", "1", true, "f32x3: norm-free LM prefill (GEMM epilogues emit split output + RMS partials); 0 = a normalisation launch per GEMM input"},
+    {"decode_fuse", "1", true, "down projection of layer l fused with q/k/v of layer l + 1 through the load-time product W'Wd; 0 = five launches per layer"},
+    {"decode_fuse_max_rb", "1", true, "largest number of 32-row blocks that runs the fused down + q/k/v launch on fp32 weights"},
+    {"splitk", "8", true, "f32x3 encoder: largest split count of the split-K launches (0 = never split; a summation order)"},
+    {"enc_apb", "0x1CC", false, "f32x3 encoder: Swin stages whose producers hand over pre-split (bit st, 4 + st, 8 + st); bit-identical"},
+    {"graph", "1", false, "decode steps as hipGraph replays (0 = eager launches)"},
+    {"fp8_decode", "1", true, "fp8 mode: e4m3 weights in the decode kernels"},
+    {"fp8_prefill", "1", true, "fp8 mode: e4m3 GEMMs in encoder + LM prefill"},
+    {"fp8_decode_act", "1", true, "fp8 mode: e4m3 activations in the decode GEMM kernels (fp8 matrix pipe)"},
+    {"fp8_kv16", "1", true, "fp8 mode: bf16 shadow of the K/V pages for the decode step"},
+    {"decode_x3", "7", true, "f32x3: mask of decode GEMM launches on the bf16 pipe (1 lm_head, 2 gate/up, 4 fused down + q/k/v)"},
+    {"decode_x3_min_rb", "2", true, "f32x3: fewest 32-row blocks at which the layer launches take their f32x3 forms"},
+    {"x3_stft", "1", true, "f32x3: STFT / mel GEMMs on the split kernel (0 = exact fp32 kernel)"},
+    {"stft_fft", "1", true, "f32x3: STFT as a 1024-point FFT when the checkpoint's conv weights are the windowed DFT basis"},
+    {"x3_apb", "1", true, "f32x3 LM prefill: producers hand over pre-split, GEMMs staged by LDS-DMA (0 = register-staged kernel on fp32 activations)"},
+    {"x3_attn", "1", true, "f32x3: prefill attention on exact bf16 splits (0 = exact fp32 MFMA kernel)"},
+    {"x3w", "1", false, "f32x3: K = 96 GEMMs on the weight-stationary persistent kernel; bit-identical"},
+    {"row_migration", "1", false, "reference-semantics loop, B > 32: rows still running are packed into the lowest 32-row blocks; tokens unchanged"},
+    {"arena_mb", "3400", false, "size of the weight arena in MiB (before the first tensor is loaded)"},
+};
+static const OptDesc* find_opt(const char* key) {
+    for (const auto& o : kOptions)
+        if (!strcmp(o.key, key)) return &o;
+    return nullptr;
+}
+static long opt_val(const mellow_engine* e, const char* key) {
+    auto it = e->opts.find(key);
+    return strtol(it != e->opts.end() ? it->second.c_str() : find_opt(key)->dflt, nullptr, 0);
+}
+// option table + precision mode -> resolved fields (the only place they are written)
+int apply_options(mellow_engine* e) {
+    const int mode = e->mode;
+    e->prefill_parts = (int)opt_val(e, "prefill_split");
+    e->prefill_fuse_norm = opt_val(e, "prefill_fuse_norm") != 0;
+    e->decode_fuse = opt_val(e, "decode_fuse") != 0;
+    e->dec_fuse_max_rb = (int)opt_val(e, "decode_fuse_max_rb");
+    e->sk_max = (int)opt_val(e, "splitk");
+    e->enc_apb_stages = (int)opt_val(e, "enc_apb");
+    e->use_graph = opt_val(e, "graph") != 0;
+    e->x3_stft = opt_val(e, "x3_stft") != 0;
+    e->stft_fft = opt_val(e, "stft_fft") != 0 && e->x3_stft;
+    e->x3_apb = opt_val(e, "x3_apb") != 0;
+    e->x3_attn = opt_val(e, "x3_attn") != 0;
+    e->x3w = opt_val(e, "x3w") != 0;
+    e->row_migration = opt_val(e, "row_migration") != 0;
+    e->arena_mb = (int)opt_val(e, "arena_mb");
+    e->fp8 = mode == MELLOW_PRECISION_FP8;
+    e->fp8_decode = e->fp8 && opt_val(e, "fp8_decode") != 0;
+    e->fp8_decode_act = e->fp8_decode && opt_val(e, "fp8_decode_act") != 0;
+    e->fp8_prefill = opt_val(e, "fp8_prefill") != 0;
+    e->kv16 = e->fp8_decode && opt_val(e, "fp8_kv16") != 0;      // fp8 mode: bf16 shadow pages for the decode step
+    // f32x3: six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64 product is
+    // identical to the nine-term form and slightly below the fp32 MFMA kernel's (tools/f32x3_check.py)
+    e->f32x3_terms = mode == MELLOW_PRECISION_F32X3 ? 6 : 0;
+    // f32x3 mode: the decode step's GEMM launches split their operands in registers and run on the bf16 pipe as well (decode.hip)
+    e->dec_x3 = mode == MELLOW_PRECISION_F32X3 ? ((int)opt_val(e, "decode_x3") & DEC_X3_ALL) : 0;
+    e->dec_x3_min_rb = (int)opt_val(e, "decode_x3_min_rb") < 1 ? 1 : (int)opt_val(e, "decode_x3_min_rb");
+    return 0;
+}
+
 extern "C" {
+
+int mellow_engine_set_option(mellow_engine_t* e, const char* key, const char* value) {
+    if (!e || !key || !value) return fail("null argument");
+    if (e->finalized) return fail("options must be set before mellow_engine_finalize");
+    const OptDesc* o = find_opt(key);
+    if (!o) return fail("unknown option \"%s\" (mellow_engine_describe lists them)", key);
+    char* end = nullptr;
+    const long v = strtol(value, &end, 0);
+    if (end == value || *end) return fail("option \"%s\": \"%s\" is not an integer", key, value);
+    if (!strcmp(key, "prefill_split") && (v < 1 || v > 4)) return fail("option prefill_split must be 1..4");
+    if (!strcmp(key, "arena_mb") && e->arena) return fail("option arena_mb must be set before the first tensor is loaded");
+    e->opts[key] = value;
+    return apply_options(e);
+}
+
+// JSON object: ABI, precision mode, every option with its resolved value, its default and whether it can change the answers,
+// and what the engine has found out about itself (prefill parts in use, STFT form).  Returns the number of bytes the text needs
+// (including the terminator); it is written only when capacity suffices.
+int64_t mellow_engine_describe(mellow_engine_t* e, char* buf, int64_t capacity) {
+    if (!e) return -1;
+    std::string s = "{\"abi\": [" + std::to_string(MELLOW_ABI_VERSION) + ", " + std::to_string(MELLOW_ABI_MINOR) + "], \"precision\": \"";
+    s += e->mode == MELLOW_PRECISION_F32 ? "f32" : e->mode == MELLOW_PRECISION_FP8 ? "fp8" : "f32x3";
+    s += "\", \"reads_environment\": false, \"finalized\": ";
+    s += e->finalized ? "true" : "false";
+    s += ", \"stft_is_fft\": ";
+    s += e->fft_win ? "true" : "false";
+    s += ", \"non_default\": [";
+    bool first = true;
+    for (const auto& o : kOptions)
+        if (opt_val(e, o.key) != strtol(o.dflt, nullptr, 0)) { s += std::string(first ? "" : ", ") + "\"" + o.key + "\""; first = false; }
+    s += "], \"options\": {";
+    first = true;
+    for (const auto& o : kOptions) {
+        s += std::string(first ? "" : ", ") + "\"" + o.key + "\": {\"value\": " + std::to_string(opt_val(e, o.key)) + ", \"default\": " +
+             std::to_string(strtol(o.dflt, nullptr, 0)) + ", \"changes_answers\": " + (o.answers ? "true" : "false") + "}";
+        first = false;
+    }
+    s += "}}";
+    if (buf && capacity > (int64_t)s.size()) memcpy(buf, s.c_str(), s.size() + 1);
+    return (int64_t)s.size() + 1;
+}
 
 int mellow_last_steps_enqueued(mellow_engine_t* e) { return e ? e->last_steps_enqueued : -1; }
 
@@ -445,29 +551,8 @@ int mellow_engine_set_precision(mellow_engine_t* e, int mode) {
     if (e->finalized) return fail("precision must be chosen before mellow_engine_finalize");
     if (mode != MELLOW_PRECISION_F32 && mode != MELLOW_PRECISION_FP8 && mode != MELLOW_PRECISION_F32X3)
         return fail("unknown precision mode %d", mode);
-    e->fp8 = mode == MELLOW_PRECISION_FP8;
-    // developer / test knobs of the fp8 mode (read here, per engine): which half of the path reads e4m3 weights
-    const char *fd = getenv("MELLOW_FP8_DECODE"), *fp = getenv("MELLOW_FP8_PREFILL");
-    e->fp8_decode = e->fp8 && !(fd && fd[0] == '0');
-    const char* fa = getenv("MELLOW_FP8_DECODE_ACT");
-    e->fp8_decode_act = e->fp8_decode && !(fa && fa[0] == '0');
-    e->fp8_prefill = !(fp && fp[0] == '0');
-    const char* fk = getenv("MELLOW_FP8_KV16");
-    e->kv16 = e->fp8_decode && !(fk && fk[0] == '0');    // fp8 mode: bf16 shadow pages for the decode step; MELLOW_FP8_KV16=0: fp32 pages
-    e->f32x3_terms = 0;
-    if (mode == MELLOW_PRECISION_F32X3) {
-        // six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64
-        // product is identical to the nine-term form and slightly below the fp32 MFMA kernel's (tools/f32x3_check.py).
-        // Developer knob: MELLOW_F32X3_TERMS=9 keeps every partial product.
-        const char* t = getenv("MELLOW_F32X3_TERMS");
-        e->f32x3_terms = (t && atoi(t) == 9) ? 9 : 6;
-    }
-    // f32x3 mode: the decode step's GEMM launches split their operands in registers and run on the bf16 pipe as well
-    // (decode.hip); MELLOW_DECODE_X3=<mask of DEC_X3_*> is the developer A/B (0 = the exact fp32 MFMA decode kernels)
-    const char* dx = getenv("MELLOW_DECODE_X3");
-    e->dec_x3 = mode == MELLOW_PRECISION_F32X3 ? (dx ? atoi(dx) & DEC_X3_ALL : DEC_X3_ALL) : 0;
-    if (const char* mr = getenv("MELLOW_DECODE_X3_MIN_RB")) e->dec_x3_min_rb = atoi(mr) < 1 ? 1 : atoi(mr);
-    return 0;
+    e->mode = mode;
+    return apply_options(e);
 }
 
 // A second execution context on the same device that SHARES the parent's weights (read-only after finalize): own HIP stream,
@@ -480,6 +565,8 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     HIPCHK(hipStreamSynchronize(parent->stream));
     mellow_engine* c = new mellow_engine();
     c->cfg = parent->cfg; c->device = parent->device; c->finalized = true; c->owns_weights = false; c->use_graph = parent->use_graph;
+    c->opts = parent->opts; c->mode = parent->mode; c->x3_stft = parent->x3_stft; c->stft_fft = parent->stft_fft; c->x3_apb = parent->x3_apb; c->x3_attn = parent->x3_attn; c->x3w = parent->x3w;
+    c->row_migration = parent->row_migration; c->decode_fuse = parent->decode_fuse; c->arena_mb = parent->arena_mb;
     c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb; c->enc_apb_stages = parent->enc_apb_stages; c->sk_max = parent->sk_max;
     c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->kv16 = parent->kv16; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3; c->dec_x3_min_rb = parent->dec_x3_min_rb;
     // weight pointers (device memory owned by the parent)

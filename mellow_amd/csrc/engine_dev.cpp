@@ -33,12 +33,13 @@ __attribute__((visibility("default"))) int mellow_dev_gemm_time(mellow_engine_t*
     return 0;
 }
 
-// one fp32 GEMM C[M][N] = A[M][K] . W[N][K]^T on host data through the exact fp32 MFMA kernel (mode 0) or the bf16x3 split
-// kernel with 6 / 9 partial products (mode 6 / 9): the accuracy tap of include/mellow_hip.h
+// one fp32 GEMM C[M][N] = A[M][K] . W[N][K]^T on host data through the exact fp32 MFMA kernel (mode 0) or the engine's f32x3
+// kernels (mode 16: A split in registers; mode 17: A pre-split in APB order, both operands by LDS-DMA): the accuracy tap of
+// include/mellow_hip.h
 int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, int K, const float* W, int N, float* C_out,
                           int iters, float* ms2) {
     if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return fail("bad argument");
-    if (mode != 0 && mode != 6 && mode != 9 && mode != 16 && mode != 17) return fail("mode must be 0, 6, 9, 16 (fused 6-term) or 17 (pre-split A, LDS-DMA)");
+    if (mode != 0 && mode != 16 && mode != 17) return fail("mode must be 0 (fp32 MFMA), 16 (f32x3, A split in registers) or 17 (f32x3, pre-split A, LDS-DMA)");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int NP = rup(N, 128);
@@ -60,8 +61,7 @@ int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, i
     auto run = [&](bool pre, bool main) {
         if (mode == 0) { if (main) launch_gemm(g, s); }
         else if (mode == 16) { if (main) launch_gemm_bf16x3_fused(g, s); }
-        else if (mode == 17) { if (pre) launch_split_rows_apb(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3_apb(g, s); }
-        else { if (pre) launch_split_rows(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3(g, mode, s); }
+        else { if (pre) launch_split_rows_apb(dA, K, M, K, dA3, s); if (main) launch_gemm_bf16x3_apb(g, s); }
     };
     run(true, true);
     HIPCHK(hipGetLastError());

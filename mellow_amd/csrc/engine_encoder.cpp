@@ -14,14 +14,13 @@ int run_gemm(mellow_engine* e, const GemmArgs& a) {
     // included (-0.6 ms per pass).  Through the split kernel the power spectrum differs from the ORACLE's fp32 conv1d by 2.5e-6
     // of its maximum -- two fp32 summation orders of a 1024-term dot product, squared -- while against an fp64 STFT it is
     // closer than the oracle's own fp32 arithmetic (tests/test_gpu_parity.py::test_encoder_taps holds it to both).
-    // MELLOW_X3_STFT=0 keeps the front-end on the exact fp32 kernel.
-    static const bool x3_stft = !(getenv("MELLOW_X3_STFT") && getenv("MELLOW_X3_STFT")[0] == '0');
+    // Option "x3_stft" = 0 keeps the front-end on the exact fp32 kernel.
+    const bool x3_stft = e->x3_stft;
     if (e->f32x3_terms && a.K % 16 == 0 &&
         ((a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) || (x3_stft && a.K >= 192))) {
         auto it = e->bf_w.find(a.Wp);
         if (it != e->bf_w.end()) {
-            // fused kernel: A stays fp32 (global and LDS) and is split into its three bf16 terms in registers; the
-            // pre-split kernel (launch_split_rows + launch_gemm_bf16x3) remains reachable through mellow_debug_gemm_f32
+            // fused kernel: A stays fp32 (global and LDS) and is split into its three bf16 terms in registers
             GemmArgs g = a;
             g.W8 = reinterpret_cast<const uint8_t*>(it->second);
             with_splitk(e, g);
@@ -62,6 +61,7 @@ int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_
     g.A8 = reinterpret_cast<const uint8_t*>(a3);
     g.W8 = reinterpret_cast<const uint8_t*>(it->second);
     if (!st || st == e->stream) with_splitk(e, g);
+    g.no_x3w = !e->x3w;
     ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
     ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 300;
     launch_gemm_bf16x3_apb(g, st ? st : e->stream);

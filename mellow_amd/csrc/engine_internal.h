@@ -26,6 +26,8 @@
 using namespace mellow;
 
 int fail(const char* fmt, ...);
+struct mellow_engine;
+int apply_options(mellow_engine* e);            // engine.cpp: option table + precision mode -> the engine's resolved fields
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -113,8 +115,16 @@ struct mellow_engine {
     mellow_config_t cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    int prefill_parts = 2;                      // parts of the split LM prefill (MELLOW_PREFILL_SPLIT, read when the engine is created)
-    bool streams_probed = false;                // a probe found NO stream that overlaps the main one: the prefill stays one chain (ensure_prefill_streams)
+    // explicit configuration (mellow_engine_set_option, engine.cpp): key -> value as given by the caller.  The library reads NO
+    // environment variable; apply_options() turns this table (+ the precision mode) into the fields below, and
+    // mellow_engine_describe() reports the resolved values.
+    std::map<std::string, std::string> opts;
+    int mode = MELLOW_PRECISION_F32X3;
+    bool x3_stft = true, stft_fft = true, x3_apb = true, x3_attn = true, x3w = true, row_migration = true, decode_fuse = true;
+    int arena_mb = 3400;
+    int prefill_parts = 2;                      // parts of the split LM prefill (option "prefill_split")
+    bool streams_probed = false;                // a probe found fewer overlapping streams than asked for (ensure_prefill_streams): re-probed after 16 calls
+    int probe_backoff = 0, prefill_parts_ok = 1, prefill_parts_want = 2;
     hipStream_t stream2[3] = {nullptr, nullptr, nullptr};      // further streams of the split LM prefill (run_prefill)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
@@ -153,7 +163,7 @@ struct mellow_engine {
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
     Buf kcache16, vcache16;      // fp8 mode: bf16 shadow of the pages for the decode step (half the floats of kcache / vcache)
-    bool kv16 = false;           // fp8 mode default; MELLOW_FP8_KV16=0 keeps the decode step on the fp32 pages
+    bool kv16 = false;           // fp8 mode default; option "fp8_kv16" = 0 keeps the decode step on the fp32 pages
     Buf lm_xn3, lm_o3, lm_h3;                  // f32x3 mode: the GEMM inputs of LM prefill, pre-split by their producers (APB order)
     Buf lm_ssq;                                // ... and the per-row sum-of-squares partials of the residual stream (norm-free chaining)
     Buf dec;                                   // one arena for the decode-step buffers (DecArgs)
@@ -188,21 +198,21 @@ struct mellow_engine {
     // fp8 GEMM mode (BASELINE config 5): every packed weight with KP % 64 == 0 also gets a P8 copy + per-row scales,
     // looked up by the fp32 packed pointer when a GEMM is issued; activations are quantised per row right before the GEMM
     bool fp8 = false;
-    bool fp8_decode = false;                     // fp8 mode: the decode kernels read e4m3 weights too (off: MELLOW_FP8_DECODE=0)
-    bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (off: MELLOW_FP8_DECODE_ACT=0)
-    bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (off: MELLOW_FP8_PREFILL=0, a test isolating the decode weights)
+    bool fp8_decode = false;                     // fp8 mode: the decode kernels read e4m3 weights too (option "fp8_decode")
+    bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (option "fp8_decode_act")
+    bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (option "fp8_prefill" = 0: a test isolating the decode weights)
     float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
-    int dec_x3_min_rb = 2;                       // ... and the fewest 32-row blocks at which the layer GEMM launches take their f32x3 forms (MELLOW_DECODE_X3_MIN_RB)
-    int dec_x3 = 0;                              // f32x3 mode: DEC_X3_* mask of the decode GEMM launches on the bf16 pipe (MELLOW_DECODE_X3=mask, developer A/B)
-    int f32x3_terms = 0;                         // 0 = off; 6 / 9 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting
+    int dec_x3_min_rb = 2;                       // ... and the fewest 32-row blocks at which the layer GEMM launches take their f32x3 forms (option "decode_x3_min_rb")
+    int dec_x3 = 0;                              // f32x3 mode: DEC_X3_* mask of the decode GEMM launches on the bf16 pipe (option "decode_x3", developer A/B)
+    int f32x3_terms = 0;                         // 0 = off; 6 = fp32 GEMMs on the bf16 pipe by exact 3-way operand splitting (six partial products)
     // f32x3 LM prefill without RMSNorm launches: the o_proj / down GEMMs write their output pre-split + its sum of squares,
     // the q/k/v and gate/up GEMMs run on norm-folded weights and scale their accumulators by the row statistic (run_prefill).
-    // MELLOW_PREFILL_FUSE_NORM=0: the two-launch form (developer A/B), read when the engine is created.
+    // option "prefill_fuse_norm" = 0: the two-launch form (developer A/B).
     bool prefill_fuse_norm = true;
     int enc_apb_stages = 0x1CC;                   // f32x3 mode: Swin stages (bit st) whose LayerNorms / fc1 hand their output over pre-split (APB) to x3q GEMMs
     Buf sk_ws;                                   // split-K workspace of the f32x3 GEMMs (512 partial tiles of 128 x 128 fp32);
     bool sk_enable = false;                      // ... only launches of the encoder chain (one stream) may use it: run_encoder switches it on
-    int sk_max = 8;                              // ... largest split count (MELLOW_SPLITK; < 2 = never split)
+    int sk_max = 8;                              // ... largest split count (option "splitk"; < 2 = never split)
     Buf enc_a3, enc_h3;                          // ... the two pre-split operands (LayerNorm output; GELU(fc1) output)
     uint64_t dbg_spans[960] = {};
     int dbg_seq0 = -1;                           // developer stamps (mellow_dev_kdebug): first launch index of a decode step, -1 = off

@@ -74,7 +74,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         // (and the logits store off: the taps mellow_lm_prefill / mellow_lm_decode_step read dlogits, generation does not)
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         a.xmidF = p + o_xmidF; a.xnewR = p + o_xnewR; a.xnF = p + o_xnF;
-        a.xn3 = (a.x3 & DEC_X3_HEAD) && !e->head8 ? (void*)(p + o_xnF) : nullptr;
+        a.xn3 = (a.x3 & DEC_X3_HEAD) && !e->head8 && dec_head3r_fits(e->cfg.vocab_size) ? (void*)(p + o_xnF) : nullptr;
         a.xmid3_32 = x3l ? (void*)(p + o_x3a) : nullptr; a.xmid3_16 = x3l ? (void*)(p + o_x3b) : nullptr; a.h3 = x3l ? (void*)(p + o_h3) : nullptr;
         a.dslabF = p + o_dslabF; a.slabF_stride4 = (int64_t)(n_x / 4); a.ssq1 = p + o_ssq1; a.rope_cur = p + o_rope;
         {
@@ -142,13 +142,12 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
     const int M = B * T, Tmax = e->kv_Tmax;
     const int NL = e->cfg.num_layers;
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
-    static const bool no_apb = getenv("MELLOW_X3_NO_APB") != nullptr;        // developer A/B: the register-staged x3p kernel
-    const bool apb = e->f32x3_terms && !no_apb;
+    const bool apb = e->f32x3_terms && e->x3_apb;        // option "x3_apb" = 0: the register-staged x3p kernel (developer A/B)
     // Split prefill (f32x3 mode): the batch is cut into independent parts (2 by default) that run the same launches on their own
     // streams, so the tails and the fill / drain of one part's kernels are covered by another's (every buffer is indexed by row
     // or by example, so a part is an offset; its pre-split operands get their own panel-aligned region).  Measured before it was
     // built with two forked contexts (tools/half_chain_probe.py).  MELLOW_PREFILL_SPLIT=n: n parts (1 = one chain, at most 4).
-    if (apb && !e->prof_on && e->prefill_parts > 1) CHK(ensure_prefill_streams(e));      // (may find that they would serialise: one chain)
+    if (apb && !e->prof_on && (e->prefill_parts > 1 || e->streams_probed)) CHK(ensure_prefill_streams(e));      // (may find that they would serialise: fewer parts)
     int nh = (apb && !e->prof_on) ? e->prefill_parts : 1;
     nh = nh < 1 ? 1 : (nh > 4 ? 4 : nh);
     if (nh > B) nh = B;
@@ -227,7 +226,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
             {
                 // causal QK^T + PV: 4*64 flops per (query,key) pair per head
                 ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)Bh * ((double)T * (T + 1) / 2), 0);
-                static const bool attn_f32 = getenv("MELLOW_X3_ATTN") && getenv("MELLOW_X3_ATTN")[0] == '0';   // A/B: f32x3 mode on the fp32 kernel
+                const bool attn_f32 = !e->x3_attn;   // option "x3_attn" = 0: f32x3 mode on the fp32 kernel (A/B)
                 launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, e->f32x3_terms != 0 && !attn_f32, st);
             }
             {
@@ -607,7 +606,7 @@ static int generate_pass(mellow_engine_t* e, const float* audio1, const float* a
 #else
     constexpr bool dev_dead = false;
 #endif
-    static const bool no_migrate = getenv("MELLOW_NO_ROW_MIGRATION") != nullptr;   // developer A/B: block exit without repacking
+    const bool no_migrate = !e->row_migration;   // option "row_migration" = 0: block exit without repacking (developer A/B)
     e->da.row_of_slot = nullptr;
     if (dev_dead) {
         e->da.blk_live = e->d_blk_live;

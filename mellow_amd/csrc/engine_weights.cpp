@@ -121,8 +121,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(expect_shape(get(e, ki), ki, {kNfreq, 1, kNfft}));
         CHK(make_packed(e, get(e, kr)->f(), get(e, ki)->f(), kNfreq, kNfft, &e->dft));
         // MELLOW_STFT_FFT=0: the DFT GEMM on the split kernel; MELLOW_X3_STFT=0: the whole front-end on the exact fp32 kernel
-        static const bool no_fft = (getenv("MELLOW_STFT_FFT") && getenv("MELLOW_STFT_FFT")[0] == '0') ||
-                                   (getenv("MELLOW_X3_STFT") && getenv("MELLOW_X3_STFT")[0] == '0');
+        const bool no_fft = !e->stft_fft;            // options "stft_fft" / "x3_stft"
         if (e->f32x3_terms && !no_fft && kNfft == 1024) {
             // the reference builds these weights as window[n] * cos / -sin(2 pi k n / N) (torchlibrosa STFT, frozen parameters);
             // a checkpoint that holds anything else keeps the GEMM.  Row k = 0 of the real part IS the window.
@@ -280,7 +279,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
     }
     // scratch for the load-time weight composition of dec_qkv2_kernel (fp32 decode weights only)
     float *cmpF = nullptr, *cmpD = nullptr, *cmpQ = nullptr, *cmpCat = nullptr;
-    const bool no_fuse = getenv("MELLOW_DECODE_FUSE") && getenv("MELLOW_DECODE_FUSE")[0] == '0';   // keep the 5-launch layer (read per engine)
+    const bool no_fuse = !e->decode_fuse;   // option "decode_fuse" = 0: keep the 5-launch layer
     const bool fuse = !no_fuse && H == 576 && I == 1536;
     if (fuse) {
         HIPCHK(hipMalloc(&cmpF, (size_t)960 * 576 * 4));

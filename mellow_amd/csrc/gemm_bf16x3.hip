@@ -1,17 +1,16 @@
 // fp32 GEMM on the bf16 matrix pipe by exact operand splitting ("bf16x3"): every fp32 operand value is the exact sum of
 // three bf16 numbers, a = a1 + a2 + a3 (8 + 8 + 8 significand bits), so a*b = sum_ij ai*bj with every partial product
 // exact in fp32; the products run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32 accumulation.
-//   TERMS = 9: all partial products -> each a*b is exact before accumulation (what the fp32 MFMA also guarantees);
-//   TERMS = 6: drops a2*b3, a3*b2, a3*b3 (< 2^-23 |a*b| in total), the order of one fp32 rounding.
+// Six partial products: a2*b3, a3*b2, a3*b3 are dropped (< 2^-23 |a*b| in total, the order of one fp32 rounding; the nine-term
+// form measured the same error against fp64 and was removed in round 6 together with its pre-split debug kernel).
 // Accumulation order differs from the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32, so results are fp32-accurate, not
 // bit-identical to that kernel; tools/f32x3_check.py measures all three against an fp64 product.
 // This is the engine's default numeric mode (MELLOW_PRECISION_F32X3, include/mellow_hip.h); the parity suite runs in it and in
 // the exact fp32 MFMA mode (MELLOW_PRECISION_F32, gemm_f32.hip) with the same tolerances and exact tokens.
 //
-//   split_rows   A fp32 [M][K] -> A3 [M][K/8][3][8 bf16]                           (one wave per row, before each GEMM)
 //   pack_bf16x3  W fp32 P-layout -> PB [n/32][k/16][3][lane][8 bf16]               (once per tensor at load time)
 //   gemm         128 x 128 tile, 4 waves, one k16 step per stage (12 KiB per operand), double-buffered LDS in
-//                fragment order, 12 ds_read_b128 feed 4 x TERMS MFMAs; shared epilogues (gemm_epilogue.h).
+//                fragment order, 12 ds_read_b128 feed 24 MFMAs; shared epilogues (gemm_epilogue.h).
 #include <cstdlib>
 
 #include "common.h"
@@ -20,28 +19,6 @@
 
 namespace mellow {
 
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ A, int64_t lda, int M, int K,
-                                                         i32x4* __restrict__ A3, int64_t ld3 /* i32x4 per row = 3 K/8 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
-    if (m >= M) return;
-    const f32x4* row = reinterpret_cast<const f32x4*>(A + (int64_t)m * lda);
-    i32x4* out = A3 + (int64_t)m * ld3;
-    const int K8 = K >> 3;
-    for (int g8 = lane; g8 < K8; g8 += 64) {
-        const f32x4 x = row[2 * g8], y = row[2 * g8 + 1];
-        const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-        i32x4 p0, p1, p2;
-        split8(v, p0, p1, p2);
-        out[3 * g8 + 0] = p0;
-        out[3 * g8 + 1] = p1;
-        out[3 * g8 + 2] = p2;
-    }
-}
-void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s) {
-    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, lda, M, K, reinterpret_cast<i32x4*>(A3),
-                       (int64_t)3 * (K >> 3));
-}
 
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ Wp, int NP, int KP, i32x4* __restrict__ PB) {
     const int K16 = KP >> 4, K8 = KP >> 3;
@@ -134,91 +111,6 @@ static int splitk_for(const GemmArgs& a, int tiles, int KT) {
 }
 
 #define MELLOW_BF(W, A, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, A), ACC, 0, 0, 0);
-
-template <int EPI, int TERMS>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmBDev p) {
-    constexpr int BM = 128, BN = 128, WN = 2;
-    constexpr int STAGE = 3 * 4 * 64;                  // 16-byte slots per operand per stage: [piece][tile][lane]
-    __shared__ __attribute__((aligned(16))) i32x4 As[2 * STAGE];
-    __shared__ __attribute__((aligned(16))) i32x4 Ws[2 * STAGE];
-    const GemmArgs& g = p.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int L = xcd_remap((int)blockIdx.x, p.gm * p.gn);
-    const int pm = L / p.gn, pn = L % p.gn;
-    const int K16 = g.K >> 4;
-    const bool wave_active = (pn * BN + wn * 64) < g.Nw;
-    const i32x4* A3 = reinterpret_cast<const i32x4*>(g.A8);
-    const i32x4* PB = reinterpret_cast<const i32x4*>(g.W8);
-    const int64_t ld3 = g.lda8;                        // i32x4 per row of A3
-
-    const i32x4* a_ptr[3];
-    int a_lds[3];
-    const i32x4* w_ptr[3];
-    int w_lds[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int c = q * 256 + tid;
-        const int row = c / 6, j = c % 6;              // 6 chunks per row per stage: (k8 half, piece)
-        int m = pm * BM + row;
-        m = m < g.M ? m : g.M - 1;
-        a_ptr[q] = A3 + (int64_t)m * ld3 + j;
-        a_lds[q] = ((j % 3) * 4 + (row >> 5)) * 64 + (row & 31) + 32 * (j / 3);
-        const int ntl = c / 192, rem = c % 192;        // W: [n-tile][piece][lane] per k16
-        w_ptr[q] = PB + ((int64_t)(pn * 4 + ntl) * K16) * 192 + rem;
-        w_lds[q] = ((rem >> 6) * 4 + ntl) * 64 + (rem & 63);
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    i32x4 ra[3], rw[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { ra[q] = a_ptr[q][0]; rw[q] = w_ptr[q][0]; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { As[a_lds[q]] = ra[q]; Ws[w_lds[q]] = rw[q]; }
-    __syncthreads();
-    for (int kt = 0; kt < K16; ++kt) {
-        const int cur = kt & 1;
-        const int ktn = kt + 1 < K16 ? kt + 1 : kt;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { ra[q] = a_ptr[q][(int64_t)ktn * 6]; rw[q] = w_ptr[q][(int64_t)ktn * 192]; }
-        if (wave_active) {
-            const i32x4* Ac = As + cur * STAGE + (2 * wm) * 64 + lane;
-            const i32x4* Wc = Ws + cur * STAGE + (2 * wn) * 64 + lane;
-            i32x4 a[2][3], w[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) { a[t][pc] = Ac[(pc * 4 + t) * 64]; w[t][pc] = Wc[(pc * 4 + t) * 64]; }
-            // smallest partial products first
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    if (TERMS == 9) {
-                        MELLOW_BF(w[ni][2], a[mi][2], acc[ni][mi])
-                        MELLOW_BF(w[ni][2], a[mi][1], acc[ni][mi])
-                        MELLOW_BF(w[ni][1], a[mi][2], acc[ni][mi])
-                    }
-                    MELLOW_BF(w[ni][2], a[mi][0], acc[ni][mi])
-                    MELLOW_BF(w[ni][0], a[mi][2], acc[ni][mi])
-                    MELLOW_BF(w[ni][1], a[mi][1], acc[ni][mi])
-                    MELLOW_BF(w[ni][1], a[mi][0], acc[ni][mi])
-                    MELLOW_BF(w[ni][0], a[mi][1], acc[ni][mi])
-                    MELLOW_BF(w[ni][0], a[mi][0], acc[ni][mi])
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { As[(cur ^ 1) * STAGE + a_lds[q]] = ra[q]; Ws[(cur ^ 1) * STAGE + w_lds[q]] = rw[q]; }
-        __syncthreads();
-    }
-    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN);
-}
 
 // ---- fused variant: A stays fp32 in global memory and in LDS and is split in registers after the fragment read -----------
 // No pre-pass, A traffic identical to the fp32 kernel; only the (pre-split, PB-layout) weight costs 6 bytes per element.
@@ -876,8 +768,7 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
     d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
-    static const bool no_ng = getenv("MELLOW_X3Q_NGROUP") && getenv("MELLOW_X3Q_NGROUP")[0] == '0';      // developer A/B
-    d.ng = (!no_ng && d.ks == 1 && d.gn % 8 == 0 && d.gn >= 16) ? 1 : 0;
+    d.ng = (d.ks == 1 && d.gn % 8 == 0 && d.gn >= 16) ? 1 : 0;
     const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                              // 72 KiB
     set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3q_kernel<EPI>), lds);
     hipLaunchKernelGGL((gemm_x3q_kernel<EPI>), dim3(d.gm * d.gn * d.ks), dim3(256), lds, s, d);
@@ -885,8 +776,7 @@ static void launchq(const GemmArgs& a, hipStream_t s) {
 }
 // K = 96, plain LINEAR epilogue (bias, optional GELU, fp32 output): the weight-stationary persistent kernel
 static bool x3w_fits(const GemmArgs& a) {
-    static const bool off = getenv("MELLOW_X3W") && getenv("MELLOW_X3W")[0] == '0';
-    return !off && a.epi == EPI_LINEAR && a.K == 96 && a.M >= 8192 && a.C && !a.C3 && !a.resid && !a.crow_map && !a.rs_ssq &&
+    return !a.no_x3w && a.epi == EPI_LINEAR && a.K == 96 && a.M >= 8192 && a.C && !a.C3 && !a.resid && !a.crow_map && !a.rs_ssq &&
            (a.act == ACT_NONE || a.act == ACT_GELU) && a.N % 4 == 0;
 }
 static void launchw(const GemmArgs& a, hipStream_t s) {
@@ -914,25 +804,13 @@ void launch_gemm_bf16x3_apb(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int EPI>
-static void launchb(const GemmArgs& a, int terms, hipStream_t s) {
-    GemmBDev d;
-    d.a = a;
-    d.gm = (a.M + 127) / 128;
-    d.gn = (a.Nw + 127) / 128;
-    d.ks = 1;
-    if (terms == 6) hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 6>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, 9>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
-}
-template <int EPI>
 static void launchbf(const GemmArgs& a, hipStream_t s) {
     GemmBDev d;
     d.a = a;
     d.gm = (a.M + 127) / 128;
     d.gn = (a.Nw + 127) / 128;
     d.ks = 1;
-    static const int ks16 = getenv("MELLOW_F32X3_KS16") ? atoi(getenv("MELLOW_F32X3_KS16")) : 1;   // k16 steps per LDS stage
-    static const bool pipelined = !(getenv("MELLOW_X3_KERNEL") && getenv("MELLOW_X3_KERNEL")[0] == 'f');   // 'f' = the plain fused kernel
-    if (pipelined && a.K % 16 == 0 && a.K >= 192) {      // shorter K: the 3-stage prologue costs more than it hides (K = 96: 77 vs 84 TF)
+    if (a.K % 16 == 0 && a.K >= 192) {      // shorter K: the 3-stage prologue costs more than it hides (K = 96: 77 vs 84 TF)
         const size_t lds = (size_t)3 * (2 * 3 * 4 * 64) * 16;                          // 72 KiB
         set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_x3p_kernel<EPI>), lds);
         d.ks = splitk_for(a, d.gm * d.gn, a.K >> 4);
@@ -940,14 +818,8 @@ static void launchbf(const GemmArgs& a, hipStream_t s) {
         if (d.ks > 1) hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), 0, s, d);
         return;
     }
-    if (ks16 == 2 && a.K % 32 == 0) {
-        const size_t lds = (size_t)2 * (2 * 2 * 4 * 64 + 2 * 3 * 4 * 64) * 16;     // 80 KiB
-        set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_bf16x3f_kernel<EPI, 2>), lds);
-        hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 2>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
-    } else {
-        const size_t lds = (size_t)2 * (2 * 4 * 64 + 3 * 4 * 64) * 16;             // 40 KiB
-        hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 1>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
-    }
+    const size_t lds = (size_t)2 * (2 * 4 * 64 + 3 * 4 * 64) * 16;                 // 40 KiB
+    hipLaunchKernelGGL((gemm_bf16x3f_kernel<EPI, 1>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
 }
 // fused variant: g.A (fp32, row-major, lda) + g.W8 (PB); K % 32 == 0; six partial products
 void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s) {
@@ -957,14 +829,6 @@ void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s) {
         case EPI_QKV_ROPE: launchbf<EPI_QKV_ROPE>(a, s); break;
         case EPI_POWER: launchbf<EPI_POWER>(a, s); break;       // A_FRAMES only through the pipelined kernel (K = 1024)
         case EPI_LOGMEL: launchbf<EPI_LOGMEL>(a, s); break;
-        default: break;
-    }
-}
-void launch_gemm_bf16x3(const GemmArgs& a, int terms, hipStream_t s) {
-    switch (a.epi) {
-        case EPI_LINEAR: launchb<EPI_LINEAR>(a, terms, s); break;
-        case EPI_SWIGLU: launchb<EPI_SWIGLU>(a, terms, s); break;
-        case EPI_QKV_ROPE: launchb<EPI_QKV_ROPE>(a, terms, s); break;
         default: break;
     }
 }

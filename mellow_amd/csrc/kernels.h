@@ -68,6 +68,7 @@ struct GemmArgs {
     // never split.  The split count depends on (M, N, K) only; a second launch sums the partials in split order.
     float* sk_ws = nullptr;
     int sk_tiles = 0, sk_max = 0;
+    bool no_x3w = false;        // engine option "x3w" = 0: K = 96 launches stay on the LDS-DMA tile kernel (developer A/B, bit-identical)
     float* ssq_out = nullptr;
     int ssq_parts = 0;
     // consumer side: every accumulator of row m is multiplied by 1 / sqrt(sum_p rs_ssq[m * rs_parts + p] / rs_dim + rs_eps)
@@ -92,9 +93,7 @@ void launch_pack_fp8(const float* Wp, int NP, int KP, uint8_t* W8, float* w_scal
 void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, a_mode == A_PLAIN
 // ---- fp32 GEMM on the bf16 matrix pipe by exact 3-way operand splitting (gemm_bf16x3.hip) ----------------------
 // operands travel in GemmArgs::A8 (A3 [M][K/8][3][8 bf16], lda8 = 16-byte units per row = 3 K/8) and GemmArgs::W8 (PB)
-void launch_split_rows(const float* A, int64_t lda, int M, int K, void* A3, hipStream_t s);
 void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s);
-void launch_gemm_bf16x3(const GemmArgs& a, int terms /* 6 or 9 partial products */, hipStream_t s);   // K % 16 == 0
 void launch_gemm_bf16x3_fused(const GemmArgs& a, hipStream_t s);
 // pre-split A in fragment order ("APB", A8) + PB weight (W8), both staged by LDS-DMA
 void launch_split_rows_apb(const float* A, int64_t lda, int M, int K, void* out, hipStream_t s);
@@ -130,7 +129,9 @@ constexpr int Q2_NPQ = 2 + Q2_HC;             // qkv slabs the fused kernel emit
 constexpr int Q2_K8 = 72 + 192;               // k-tiles of a Wq2 row: [W' (576 columns) | W' Wd (1536 columns)]
 constexpr int Q2_BLOCKS = 60 + 48 * Q2_HC;    // workgroups per row block
 static_assert(Q2_NPQ <= DEC_KC_QKV && Q2_HC <= DEC_KC_DOWN, "the fused kernel reuses the slab buffers of the split-K kernels");
-enum { DEC_X3_HEAD = 1, DEC_X3_GATEUP = 2, DEC_X3_QKV = 4, DEC_X3_DOWN = 8, DEC_X3_ALL = 15 };
+// engine option "decode_x3": bit 1 the lm_head on the streaming f32x3 kernel; bits 2 AND 4 together the layer launches (gate/up and the
+// fused down + q/k/v exchange pre-split activations, so they switch as a pair: engine_lm.cpp ensure_lm)
+enum { DEC_X3_HEAD = 1, DEC_X3_GATEUP = 2, DEC_X3_QKV = 4, DEC_X3_ALL = 7 };
 struct DecArgs {
     int rows = 0, RB = 0;          // padded batch rows (multiple of 32), row blocks
     int Tmax = 0;
@@ -204,6 +205,7 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const 
 void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_final_norm(const DecArgs& a, const float* norm_w, int kcd, hipStream_t s);
+bool dec_head3r_fits(int vocab);     // the streaming f32x3 lm_head tiles this vocabulary (else xn3 must stay null: fp32 xnF + the fp32 kernel)
 void launch_dec_lm_head(const DecArgs& a, const float* Wp, int K8p, int vocab, hipStream_t s, const float* wscale = nullptr);
 // Generation-loop bookkeeping that lives on the device (reference wrapper.py:232-249), written by the arg-max kernel:
 // the token is recorded at column (*d_pos - T0 + 1) of out_tokens, rows that produced the stop id are counted once, and

@@ -190,6 +190,9 @@ constexpr int PAX_LOADERS = MELLOW_PAX_LOADERS, PAX_THREADS = (3 + PAX_LOADERS) 
 #define MELLOW_PAX_MINW 2      // waves per SIMD the register allocation must allow (2 workgroups of 4 waves per CU)
 #endif
 constexpr int PAX_K_SLOTS = 4 * 3 * 64, PAX_V_SLOTS = 2 * 2 * 3 * 64;
+#ifndef MELLOW_PAX_ABL
+#define MELLOW_PAX_ABL 0      // developer ablations (wrong results, timing only; tools/microbench/prefill_attn_bench.hip): 1 loader stores
+#endif                        // unsplit bits, 2 no softmax arithmetic, 4 no split of P, 8 no score MFMAs, 16 no PV MFMAs, 32 loader fetches tile 0 only
 __device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
 #define PAX_MFMA(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
 // the six partial products of (a0 + a1 + a2)(b0 + b1 + b2) that are not below 2^-23 of the result, smallest first
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
                 const float v[8] = {pk[2 * i][0], pk[2 * i][1], pk[2 * i][2], pk[2 * i][3],
                                     pk[2 * i + 1][0], pk[2 * i + 1][1], pk[2 * i + 1][2], pk[2 * i + 1][3]};
                 i32x4 p0, p1, p2;
-                split8(v, p0, p1, p2);
+                if (MELLOW_PAX_ABL & 1) { p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; p2 = p0; } else split8(v, p0, p1, p2);
                 i32x4* dst = &Kp[st][((oct >> 1) * 3) * 64 + klo + 8 * i + 32 * (oct & 1)];
                 dst[0] = p0; dst[64] = p1; dst[128] = p2;
             }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
             for (int e = 0; e < 4; ++e) {
                 const float v[8] = {pv[0][e], pv[1][e], pv[2][e], pv[3][e], pv[4][e], pv[5][e], pv[6][e], pv[7][e]};
                 i32x4 p0, p1, p2;
-                split8(v, p0, p1, p2);
+                if (MELLOW_PAX_ABL & 1) { p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; p2 = p0; } else split8(v, p0, p1, p2);
                 const int d = 4 * q4 + e;
                 i32x4* dst = &Vp[st][((t2 * 2 + (d >> 5)) * 3) * 64 + pax_sw((d & 31) + 32 * hv)];
                 dst[0] = p0; dst[64] = p1; dst[128] = p2;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         __syncthreads();                                   // tile 0 visible
         for (int kt = 0; kt <= qt; ++kt) {
             stage((kt + 1) & 1);                           // tile kt+1 (or a harmless re-read past the end) -> other stage
-            fetch(kt + 2 <= qt ? kt + 2 : qt);
+            if (!(MELLOW_PAX_ABL & 32)) fetch(kt + 2 <= qt ? kt + 2 : qt);
             __syncthreads();                               // compute waves are done with stage kt & 1; stage (kt+1) & 1 is visible
         }
         return;
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         for (int s = 0; s < 2; ++s) {
             const i32x4 a0 = Kc[(s * 3 + 0) * 64], a1 = Kc[(s * 3 + 1) * 64], a2 = Kc[(s * 3 + 2) * 64];
             const i32x4 c0 = Kc[((s + 2) * 3 + 0) * 64], c1 = Kc[((s + 2) * 3 + 1) * 64], c2 = Kc[((s + 2) * 3 + 2) * 64];
+            if (MELLOW_PAX_ABL & 8) { S[0] += __int_as_float(a0[0] ^ a1[1] ^ a2[2] ^ c0[0] ^ c1[1] ^ c2[2]); continue; }
             PAX_MFMA(a2, qp[s][0], S);      PAX_MFMA(c2, qp[s + 2][0], S2);
             PAX_MFMA(a1, qp[s][1], S);      PAX_MFMA(c1, qp[s + 2][1], S2);
             PAX_MFMA(a0, qp[s][2], S);      PAX_MFMA(c0, qp[s + 2][2], S2);
@@ -311,6 +315,12 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] += S2[r];
         // lane: query ql, keys k0 + (r&3) + 8(r>>2) + 4h
+        float p[16];
+        if (MELLOW_PAX_ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = S[r];
+            l_run += S[0];
+        } else {
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -322,7 +332,6 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = pa_exp(m_run - m_new);
         float rsum = 0.f;
-        float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             p[r] = pa_exp(S[r] - m_new);
@@ -333,15 +342,18 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+        }
         // O^T[d][query] += sum_key V[key][d] P^T[key][query]: registers 8 t .. 8 t + 7 of P are the k-slots of key step t
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float v[8] = {p[8 * t], p[8 * t + 1], p[8 * t + 2], p[8 * t + 3], p[8 * t + 4], p[8 * t + 5], p[8 * t + 6], p[8 * t + 7]};
             i32x4 b0, b1, b2;
-            split8(v, b0, b1, b2);
+            if (MELLOW_PAX_ABL & 4) { b0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; b1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; b2 = b0; }
+            else split8(v, b0, b1, b2);
             {       // the two d-halves are independent chains: interleave them
                 const i32x4 a0 = Vc[((t * 2 + 0) * 3 + 0) * 64], a1 = Vc[((t * 2 + 0) * 3 + 1) * 64], a2 = Vc[((t * 2 + 0) * 3 + 2) * 64];
                 const i32x4 c0 = Vc[((t * 2 + 1) * 3 + 0) * 64], c1 = Vc[((t * 2 + 1) * 3 + 1) * 64], c2 = Vc[((t * 2 + 1) * 3 + 2) * 64];
+                if (MELLOW_PAX_ABL & 16) { O0[0] += __int_as_float(a0[0] ^ a1[1] ^ a2[2] ^ b0[0] ^ b1[1] ^ b2[2]); O1[0] += __int_as_float(c0[0] ^ c1[1] ^ c2[2]); continue; }
                 PAX_MFMA(a2, b0, O0);      PAX_MFMA(c2, b0, O1);
                 PAX_MFMA(a1, b1, O0);      PAX_MFMA(c1, b1, O1);
                 PAX_MFMA(a0, b2, O0);      PAX_MFMA(c0, b2, O1);

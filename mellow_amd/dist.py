@@ -36,17 +36,25 @@ def examples_signature(examples) -> bytes:
     n = 0
     for ex in examples:
         n += 1
-        for item in ex:
+        for slot, item in enumerate(ex):
             if isinstance(item, (str, bytes)) or hasattr(item, "__fspath__"):
                 b = item if isinstance(item, bytes) else str(item).encode()
                 h.update(b"s" + len(b).to_bytes(8, "little") + b)
-                # a path that names a file on this rank: its size and mtime go in too, so that same-named but different files on
-                # different nodes do not pass for the same example (a prompt string is not a file: nothing is added)
-                try:
-                    st = os.stat(item)
-                    h.update(b"f" + int(st.st_size).to_bytes(8, "little") + int(st.st_mtime_ns).to_bytes(16, "little", signed=True))
-                except (OSError, ValueError, TypeError):
-                    pass
+                # An AUDIO slot (index 0 / 1) that names a file on this rank: its size and a digest of its first and last 64 KiB
+                # go in too, so that same-named but different files on different nodes do not pass for the same example.  No
+                # mtime (copies of one file on two nodes differ in it), and the prompt slot is never looked up on disk (a prompt
+                # that happens to name a file in one rank's working directory is still the same prompt).
+                if slot < 2:
+                    try:
+                        size = os.path.getsize(item)
+                        h.update(b"f" + int(size).to_bytes(8, "little"))
+                        with open(item, "rb") as f:
+                            h.update(f.read(65536))
+                            if size > 131072:
+                                f.seek(size - 65536)
+                                h.update(f.read(65536))
+                    except (OSError, ValueError, TypeError):
+                        pass
             else:
                 a = np.ascontiguousarray(torch.as_tensor(item).detach().cpu().numpy(), dtype=np.float32)
                 h.update(b"a" + repr(a.shape).encode() + a.tobytes())

@@ -92,6 +92,8 @@ def load_library(path: Optional[str] = None):
         "mellow_prefill_parts": (ci, [vp]),
         "mellow_abi_minor": (ci, []),
         "mellow_engine_set_precision": (ci, [vp, ci]),
+        "mellow_engine_set_option": (ci, [vp, C.c_char_p, C.c_char_p]),
+        "mellow_engine_describe": (i64, [vp, C.c_char_p, i64]),
         "mellow_set_graph": (ci, [vp, ci]),
         "mellow_host_window_map": (ci, [ci, ci, P(C.c_int32)]),
         "mellow_host_pack_weight": (ci, [P(cf), ci, ci, ci, P(cf), i64]),
@@ -115,7 +117,7 @@ EXPORTED_SYMBOLS = (
     "mellow_encode", "mellow_prefix", "mellow_lm_prefill", "mellow_lm_decode_step", "mellow_argmax", "mellow_embed_tokens", "mellow_lm_forward_logits",
     "mellow_debug_enable_taps", "mellow_debug_tap", "mellow_prof_enable", "mellow_prof_reset",
     "mellow_prof_num_families", "mellow_prof_family_name", "mellow_prof_get", "mellow_last_phase_ms", "mellow_last_steps_enqueued", "mellow_last_row_repacks", "mellow_stft_is_fft", "mellow_prefill_parts", "mellow_abi_minor",
-    "mellow_resample", "mellow_engine_set_precision", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_debug_dec_head", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
+    "mellow_resample", "mellow_engine_set_precision", "mellow_engine_set_option", "mellow_engine_describe", "mellow_debug_gemm_fp8", "mellow_debug_gemm_f32", "mellow_debug_dec_head", "mellow_set_graph", "mellow_host_window_map", "mellow_host_pack_weight", "mellow_host_rope_tables",
 )
 
 
@@ -136,7 +138,7 @@ class Engine:
     """One engine per device.  Inputs/outputs are torch tensors on that device (plumbing only)."""
 
     def __init__(self, lm: Optional[LMConfig] = None, device: int = 0, max_positions: Optional[int] = None,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, options: Optional[Dict[str, int]] = None):
         self.lib = load_library()
         if self.lib.mellow_device_count() <= 0:
             raise EngineError("no HIP device visible: the Mellow engine needs an MI355X (no CPU fallback)")
@@ -166,6 +168,21 @@ class Engine:
             raise ValueError(f"unknown precision {precision!r}")
         self.precision = precision
         self._chk(self.lib.mellow_engine_set_precision(self.h, {"f32": 0, "fp8": 1, "f32x3": 2}[precision]))
+        # explicit configuration (include/mellow_hip.h: mellow_engine_set_option): the library reads no environment variable; the
+        # A/B forms the tests and tools compare are selected here, by name, and show up in describe()["non_default"]
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, key: str, value) -> None:
+        self._chk(self.lib.mellow_engine_set_option(self.h, key.encode(), str(int(value)).encode()))
+
+    def describe(self) -> dict:
+        """the engine's resolved configuration (mellow_engine_describe): precision, every option with value / default, ABI"""
+        import json
+        n = int(self.lib.mellow_engine_describe(self.h, None, 0))
+        buf = C.create_string_buffer(n)
+        self.lib.mellow_engine_describe(self.h, buf, n)
+        return json.loads(buf.value.decode())
 
     # ---- errors ------------------------------------------------------------------------------------
     def _chk(self, rc: int):

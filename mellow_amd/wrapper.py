@@ -60,13 +60,16 @@ class MellowWrapper:
 
     def __init__(self, config, model, device, use_cuda=True, *, checkpoint: Optional[str] = None,
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None, max_positions: Optional[int] = None,
-                 data_parallel: Optional[bool] = None, precision: Optional[str] = None):
+                 data_parallel: Optional[bool] = None, precision: Optional[str] = None,
+                 engine_options: Optional[Dict[str, int]] = None):
         """Reference signature `MellowWrapper(config, model, device, use_cuda=True)` (wrapper.py:35) plus keyword-only
         extensions: `checkpoint` (a local .ckpt instead of the hub download), `state_dict` (already loaded), `tokenizer`
         (an object with encode / encode_plus / decode), `max_positions` (prefix 389 + max_len may not exceed it; default: the LM's
         max_position_embeddings, 8192), `data_parallel` (True or MELLOW_DATA_PARALLEL=1: shard `generate` over the ranks of an
         initialised torch.distributed group, one process per GPU, every rank calling with the SAME examples -- checked; default
-        off: like the reference, every process answers its own examples), `precision` ("f32x3" (default) | "f32" | "fp8")."""
+        off: like the reference, every process answers its own examples), `precision` ("f32x3" (default) | "f32" | "fp8"),
+        `engine_options` (named options of the HIP library, mellow_engine_set_option; default none: the library's defaults --
+        the library itself reads no environment variable)."""
         self.supported_versions = self.model_name.keys()
         if model not in self.supported_versions:
             raise ValueError(f"The model {model} is not supported. The supported versions are {str(self.supported_versions)}")
@@ -82,6 +85,7 @@ class MellowWrapper:
         # numeric mode of the dense GEMMs (include/mellow_hip.h): "f32x3" fp32-accurate bf16-split (default = the mode
         # bench.py reports), "f32" exact fp32 MFMA, "fp8" BASELINE config 5; keyword or MELLOW_PRECISION
         self._precision = precision or os.environ.get("MELLOW_PRECISION") or DEFAULT_PRECISION
+        self._engine_options = dict(engine_options or {})
         self.model, self.tokenizer, self.args = self.get_model_and_tokenizer(config_path=self.config_path)
 
     # ---- construction -------------------------------------------------------------------------------------
@@ -124,7 +128,8 @@ class MellowWrapper:
         if not self.use_cuda or isinstance(self.device, str):
             raise RuntimeError("MellowWrapper (MI355X engine) has no CPU path: pass use_cuda=True and an integer device")
         lm = LMConfig.load()
-        engine = Engine(lm=lm, device=int(self.device), max_positions=self._max_positions, precision=self._precision)
+        engine = Engine(lm=lm, device=int(self.device), max_positions=self._max_positions, precision=self._precision,
+                        options=self._engine_options)
         sd = self._state_dict
         if sd is None:
             sd = torch.load(self.model_path, map_location=torch.device("cpu"))

@@ -111,11 +111,11 @@ print("rank", rank, "ok")
 '''
 
 
-def _torchrun(args, port, extra_env=None, timeout=1500):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="8",
+def _torchrun(args, port, extra_env=None, timeout=1500, nproc=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=str(max(1, 16 // nproc)),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
@@ -229,3 +229,84 @@ def test_two_replicas_load_concurrently_and_fit(tmp_path):
         secs, gib = float(l.split()[1]), float(l.split()[4])
         assert secs < 300 and gib < 16, l
     print(lines)
+
+
+# ---- eight ranks (BASELINE configs[2] / [4]: 8 x MI355X) on the one GPU of this box, over gloo ------------------------------------
+_WORKER8 = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mellow_amd import dist as mdist, synth, MellowWrapper
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+_COLL = ("all_gather", "all_gather_into_tensor", "all_gather_object", "all_reduce", "broadcast", "broadcast_object_list", "gather",
+         "scatter", "reduce", "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "barrier", "send", "recv")
+_calls = []
+def _count(name, fn):
+    def w(*a, **k):
+        _calls.append(name)
+        return fn(*a, **k)
+    return w
+for _n in _COLL:
+    if hasattr(dist, _n):
+        setattr(dist, _n, _count(_n, getattr(dist, _n)))
+class Tok:
+    def encode(self, s): return [0] if s == "<|endoftext|>" else [17 + (sum(s.encode()) * 7919 + i * 104729) % 49000 for i, _ in enumerate(s.split())]
+    def encode_plus(self, text, max_length=129, **kw):
+        ids = self.encode(text)[:max_length]
+        return {"input_ids": torch.tensor([ids + [1] * (max_length - len(ids))]), "attention_mask": torch.tensor([[1] * max_length])}
+    def decode(self, ids): return " ".join("<|endoftext|>" if int(i) == 0 else f"t{int(i)}" for i in ids)
+sd = synth.make_state_dict(0)
+# eight replicas load AT ONCE on one device (8 x (weights + workspaces) of 288 GB), eight host polling threads under the cgroup
+m = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=True, max_positions=512)
+# 19 in-memory examples over 8 ranks: shards of ceil(19 / 8) = 3 -> ranks 0..5 hold 3, rank 6 holds 1, rank 7 holds NONE
+n = 19
+a1, a2, _ = synth.make_batch(n, n_samples=2 * 32000)
+examples = [[a1[i], a2[i], f"question number {i} about the two clips"] for i in range(n)]
+del _calls[:]
+got = m.generate(examples=examples, max_len=5, top_p=0.8, temperature=1.0)
+assert _calls == ["all_gather"], _calls            # the same-examples agreement of the 8 ranks runs over the store, not a collective
+assert len(got) == n
+# every rank holds the full, ordered answer list, and it equals the un-sharded answers (computed by rank 0 alone, sent by the store)
+store = dist.distributed_c10d._get_default_store()
+if rank == 0:
+    alone = MellowWrapper(config="v0", model="v0", device=0, use_cuda=True, state_dict=sd, tokenizer=Tok(), data_parallel=False, max_positions=512)
+    want = alone.generate(examples=examples, max_len=5, top_p=0.8, temperature=1.0)
+    store.set("want8", "\x1f".join(want))
+want = store.get("want8").decode().split("\x1f")
+assert got == want, (rank, got[:3], want[:3])
+try:                                               # one rank out of eight with another list: refused on all eight
+    m.generate(examples=examples[: n - (1 if rank == 5 else 0)], max_len=5, top_p=0.8, temperature=1.0)
+    raise SystemExit("mismatching example lists were accepted")
+except ValueError as e:
+    assert "different `examples`" in str(e), e
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "of 8 ok")
+"""
+
+
+def test_eight_ranks_shard_agree_and_gather_on_one_gpu(tmp_path):
+    """8-GPU readiness without an 8-GPU node: eight processes (the launcher line of the driver, gloo instead of RCCL, all on GPU
+    0) each create a wrapper + engine replica at the same time, agree on the example list through the rendezvous store with eight
+    participants, answer ragged shards (3, 3, 3, 3, 3, 3, 1, 0 examples) and take part in exactly ONE all_gather."""
+    script = tmp_path / "dp_worker8.py"
+    script.write_text(_WORKER8)
+    r = _torchrun([str(script), ROOT], 29761, nproc=8, timeout=2400)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.stdout.count("of 8 ok") == 8
+
+
+def test_bench_eight_ranks_prints_one_line_with_n_gpus_8():
+    """The driver's `--gpus 8` launch line with all ranks on GPU 0 over gloo: one JSON line, `ranks_seen` 8 from
+    `dist.get_world_size()`, global batch 8 x 4, weak scaling, the library at its default configuration on every rank."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4"], 29763,
+                  {"MELLOW_BENCH_BACKEND": "gloo", "MELLOW_BENCH_DEVICE": "0"}, timeout=2400, nproc=8)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp8"
+    assert out["engine"]["non_default"] == [] and out["engine"]["reads_environment"] is False

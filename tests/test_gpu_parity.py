@@ -941,14 +941,12 @@ def test_config4_shape_30s_clips_max_len_128(engine, golden_dir):
 
 def test_fused_and_five_launch_decode_layers_agree(engine_f32, synth_sd, monkeypatch, golden_dir):
     """The decode layer runs as 4 launches (the down projection of a layer and the q/k/v projection of the next one in one kernel,
-    on the weight W'Wd composed at load time) or, with MELLOW_DECODE_FUSE=0, as the 5 launches of round 2.  Both must give the
+    on the weight W'Wd composed at load time) or, with the engine option decode_fuse = 0, as the 5 launches of round 2.  Both must give the
     reference's tokens (the fused form is what every other test exercises); their last-position logits differ only by fp32
     summation-order noise.  B = 2 for 40 steps, and B = 33 (two row blocks, the second with one row)."""
     from mellow_amd.engine import Engine
-    monkeypatch.setenv("MELLOW_DECODE_FUSE", "0")
-    e5 = Engine(device=0, precision="f32")
+    e5 = Engine(device=0, precision="f32", options={"decode_fuse": 0})
     e5.load_state_dict(synth_sd)
-    monkeypatch.delenv("MELLOW_DECODE_FUSE")
     try:
         g = np.load(os.path.join(golden_dir, "late.npz"))
         a1, a2, ids = synth.make_batch(2)
@@ -972,15 +970,13 @@ def test_fused_and_five_launch_decode_layers_agree(engine_f32, synth_sd, monkeyp
 
 def test_split_prefill_is_bit_identical_to_one_chain(synth_sd, monkeypatch):
     """f32x3 mode runs the LM prefill as two independent half-batches on two streams (engine_lm.cpp run_prefill; 1 / 3 / 4 parts by
-    MELLOW_PREFILL_SPLIT).  A row's arithmetic does not depend on which rows share its launch, so logits and tokens must be
+    the engine option prefill_split).  A row's arithmetic does not depend on which rows share its launch, so logits and tokens must be
     BIT-identical to the one-chain form, for batches that split unevenly (3, 5), not at all (1) and into four parts (9)."""
     from mellow_amd.engine import Engine
     engs = {}
     for parts in ("1", "2", "4"):
-        monkeypatch.setenv("MELLOW_PREFILL_SPLIT", parts)
-        engs[parts] = Engine(device=0, precision="f32x3")
+        engs[parts] = Engine(device=0, precision="f32x3", options={"prefill_split": int(parts)})
         engs[parts].load_state_dict(synth_sd)
-    monkeypatch.delenv("MELLOW_PREFILL_SPLIT")
     for B in (1, 3, 5, 9):
         a1, a2, ids = synth.make_batch(B)
         pre = engs["1"].prefix(a1, a2, ids)
@@ -998,13 +994,11 @@ def test_norm_free_prefill_agrees_with_the_two_launch_form(synth_sd, monkeypatch
     """f32x3 LM prefill without RMSNorm launches (round 4, engine_lm.cpp run_prefill): the o_proj / down GEMMs emit their output
     pre-split together with its sum-of-squares partials, the q/k/v and gate/up GEMMs run on norm-folded weights and scale their
     accumulators by the row statistic.  Against the form with a normalisation launch in front of each of those GEMMs
-    (MELLOW_PREFILL_FUSE_NORM=0): same tokens, last-position and all-position logits within a third of the 3e-3 the mode is held
+    (engine option prefill_fuse_norm = 0): same tokens, last-position and all-position logits within a third of the 3e-3 the mode is held
     to against the reference (both forms pass the reference tests on their own: the `engine` fixture runs the default)."""
     from mellow_amd.engine import Engine
-    monkeypatch.setenv("MELLOW_PREFILL_FUSE_NORM", "0")
-    e2 = Engine(device=0, precision="f32x3")
+    e2 = Engine(device=0, precision="f32x3", options={"prefill_fuse_norm": 0})
     e2.load_state_dict(synth_sd)
-    monkeypatch.delenv("MELLOW_PREFILL_FUSE_NORM")
     e1 = Engine(device=0, precision="f32x3")
     e1.load_state_dict(synth_sd)
     try:
@@ -1031,25 +1025,21 @@ def test_encoder_presplit_handover_and_splitk_agree_with_the_plain_form(synth_sd
     GELU epilogue of fc1 hand their output over pre-split (APB) and qkv / proj / fc1 / fc2 run on the LDS-DMA kernel; in stage 0
     the LayerNorms hand over pre-split and the K = 96 GEMMs qkv / fc1 run on the weight-stationary persistent kernel
     (gemm_x3w_kernel; B = 32 here is what reaches its M >= 8192 rows); launches of <= 256 output tiles (stage 3 fc2, the
-    token-semantic conv, small batches) are split along K with a fixed summation order.  Against the plain form (MELLOW_ENC_APB=0, MELLOW_SPLITK=0: fp32 hand-over, register-staged kernel, no
+    token-semantic conv, small batches) are split along K with a fixed summation order.  Against the plain form (engine options enc_apb = 0, splitk = 0: fp32 hand-over, register-staged kernel, no
     split): the encoder output within 2e-5 of its maximum (both forms pass the oracle / reference taps on their own: the
     `engine` fixture runs the default), the same tokens; and every single switch on its own as well."""
     from mellow_amd.engine import Engine
 
-    def make(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        e = Engine(device=0, precision="f32x3")
+    def make(options):
+        e = Engine(device=0, precision="f32x3", options=options)
         e.load_state_dict(synth_sd)
-        for k in env:
-            monkeypatch.delenv(k)
         return e
 
-    plain = make({"MELLOW_ENC_APB": "0", "MELLOW_SPLITK": "0"})
-    forms = {"default": make({}), "all stages": make({"MELLOW_ENC_APB": "0xFF"}), "no split-K": make({"MELLOW_SPLITK": "0"}),
-             "split-K only": make({"MELLOW_ENC_APB": "0"}), "no proj hand-over": make({"MELLOW_ENC_APB": "0x0E"}),
-             "stage 0 without the weight-stationary kernel": make({"MELLOW_ENC_APB": "0xCC"}),
-             "stage 0 pre-split on the tile kernels": make({"MELLOW_X3W": "0"})}
+    plain = make({"enc_apb": 0, "splitk": 0})
+    forms = {"default": make({}), "all stages": make({"enc_apb": 0xFF}), "no split-K": make({"splitk": 0}),
+             "split-K only": make({"enc_apb": 0}), "no proj hand-over": make({"enc_apb": 0x0E}),
+             "stage 0 without the weight-stationary kernel": make({"enc_apb": 0xCC}),
+             "stage 0 pre-split on the tile kernels": make({"x3w": 0})}
     try:
         for B in (1, 3, 32):
             a1, a2, ids = synth.make_batch(B)
@@ -1142,7 +1132,7 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
     """BASELINE config 5, decode half: the five decode GEMM kernels read e4m3 weights (one scale per packed weight row, values
     widened in registers, fp32 activations and accumulation).  Isolation: a checkpoint whose LM matrices are ALREADY e4m3-
     representable per output row (quantise -> dequantise in torch; RMSNorm weights 1 so that folding them into the decode
-    operands changes nothing) goes (a) into an fp8 engine with its e4m3 PREFILL switched off (MELLOW_FP8_PREFILL=0) and (b) into
+    operands changes nothing) goes (a) into an fp8 engine with its e4m3 PREFILL switched off (engine option fp8_prefill = 0) and (b) into
     a plain fp32 engine.  Re-quantising is the identity, so both must produce the same decode-step logits up to fp32 rounding
     (the scale is applied after the reduction instead of per weight), over 6 teacher-forced steps, and the same tokens."""
     from mellow_amd.engine import Engine
@@ -1155,20 +1145,10 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
     for k in sd:
         if k.endswith("input_layernorm.weight") or k.endswith("post_attention_layernorm.weight"):
             sd[k] = torch.ones_like(sd[k])
-    os.environ["MELLOW_FP8_PREFILL"] = "0"
-    os.environ["MELLOW_FP8_DECODE_ACT"] = "0"              # fp32 activations: the weights are the only quantised operand here
-    os.environ["MELLOW_FP8_KV16"] = "0"                    # ... and fp32 K/V pages (the mode's bf16 shadow pages have their own test below)
-    try:
-        e8 = Engine(device=0, precision="fp8")
-    finally:
-        del os.environ["MELLOW_FP8_PREFILL"]
-        del os.environ["MELLOW_FP8_DECODE_ACT"]
-        del os.environ["MELLOW_FP8_KV16"]
-    os.environ["MELLOW_DECODE_FUSE"] = "0"                 # the fused launch multiplies by W' Wd, which is not an e4m3 matrix
-    try:
-        e8.load_state_dict(sd)
-    finally:
-        del os.environ["MELLOW_DECODE_FUSE"]
+    # fp32 activations (the weights are the only quantised operand here), fp32 K/V pages (the mode's bf16 shadow pages have their
+    # own test below), and no fused launch: it multiplies by W' Wd, which is not an e4m3 matrix
+    e8 = Engine(device=0, precision="fp8", options={"fp8_prefill": 0, "fp8_decode_act": 0, "fp8_kv16": 0, "decode_fuse": 0})
+    e8.load_state_dict(sd)
     e32 = Engine(device=0, precision="f32")
     e32.load_state_dict(sd)
     a1, a2, ids = synth.make_batch(3)
@@ -1187,11 +1167,7 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
     e0 = Engine(device=0, precision="f32")
     e0.load_state_dict(synth_sd)
     l0 = e0.lm_prefill(e0.prefix(a1, a2, ids), reserve=2)
-    os.environ["MELLOW_FP8_PREFILL"] = "0"
-    try:
-        e8b = Engine(device=0, precision="fp8")
-    finally:
-        del os.environ["MELLOW_FP8_PREFILL"]
+    e8b = Engine(device=0, precision="fp8", options={"fp8_prefill": 0})
     e8b.load_state_dict(synth_sd)
     l8b = e8b.lm_prefill(e8b.prefix(a1, a2, ids), reserve=2)
     rel = float((l8b - l0).pow(2).mean().sqrt() / l0.pow(2).mean().sqrt())
@@ -1203,17 +1179,13 @@ def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_d
 def test_fp8_mode_bf16_kv_shadow_pages(synth_sd):
     """fp8 mode: the decode step reads and extends a bf16 SHADOW of the K/V pages -- half the bytes of the step's
     largest stream (at B = 128 the step reads 2.5 GB of fp32 K/V against 0.13 GB of e4m3 weights).  Against the same engine
-    on fp32 pages (MELLOW_FP8_KV16=0) the teacher-forced decode logits stay well inside the fp8 mode's own distance from the
+    on fp32 pages (engine option fp8_kv16 = 0) the teacher-forced decode logits stay well inside the fp8 mode's own distance from the
     fp32 engine (0.26 relative rms): the e4m3 activation rounding amplifies the 2^-9 perturbation of K and V to a measured
     8e-2 relative rms (bound 0.25); finite and deterministic, at B = 3 and B = 40 (two row blocks).  Token agreement with the
     fp32 engine is the same with either page format (profiles/r05_fp8_agreement*.txt: position-wise 0.705 / 0.680)."""
     from mellow_amd.engine import Engine
     ea = Engine(device=0, precision="fp8")
-    os.environ["MELLOW_FP8_KV16"] = "0"
-    try:
-        eb = Engine(device=0, precision="fp8")
-    finally:
-        del os.environ["MELLOW_FP8_KV16"]
+    eb = Engine(device=0, precision="fp8", options={"fp8_kv16": 0})
     ea.load_state_dict(synth_sd)
     eb.load_state_dict(synth_sd)
     for B in (3, 40):
@@ -1270,30 +1242,18 @@ def test_fp8_decode_activation_quantisation_is_exact_on_representable_rows(synth
 
 
 def test_fp8_decode_on_the_fp8_pipe_stays_near_the_fp32_activation_form(synth_sd):
-    """Whole decode steps, e4m3 weights in both engines, activations fp32 (MELLOW_FP8_DECODE_ACT=0) against e4m3 on the fp8
+    """Whole decode steps, e4m3 weights in both engines, activations fp32 (engine option fp8_decode_act = 0) against e4m3 on the fp8
     matrix pipe (the default of the fp8 mode): five GEMM kernels per layer quantise their inputs, so the logits differ at the
     percent level -- a wrong lane/byte assignment in any of them would give an O(1) difference -- and stay deterministic."""
     from mellow_amd.engine import Engine
-    os.environ["MELLOW_FP8_PREFILL"] = "0"
-    os.environ["MELLOW_FP8_DECODE_ACT"] = "0"
-    try:
-        ew = Engine(device=0, precision="fp8")
-    finally:
-        del os.environ["MELLOW_FP8_DECODE_ACT"]
-    try:
-        ea = Engine(device=0, precision="fp8")
-    finally:
-        del os.environ["MELLOW_FP8_PREFILL"]
+    ew = Engine(device=0, precision="fp8", options={"fp8_prefill": 0, "fp8_decode_act": 0})
+    ea = Engine(device=0, precision="fp8", options={"fp8_prefill": 0})
     ew.load_state_dict(synth_sd)
     ea.load_state_dict(synth_sd)
     # ... and the fp8 mode's fused launch (down of layer l + q/k/v of layer l+1 on the e4m3 copy of W' Wd, decode.hip) against
     # the five-launch layer on the same engine settings
-    eu = Engine(device=0, precision="fp8")
-    os.environ["MELLOW_DECODE_FUSE"] = "0"
-    try:
-        eu.load_state_dict(synth_sd)
-    finally:
-        del os.environ["MELLOW_DECODE_FUSE"]
+    eu = Engine(device=0, precision="fp8", options={"decode_fuse": 0})
+    eu.load_state_dict(synth_sd)
     ef = Engine(device=0, precision="fp8")
     ef.load_state_dict(synth_sd)
     for B in (3, 40):
@@ -1372,7 +1332,7 @@ def test_f32x3_mode_is_fp32_accurate(engine_f32, synth_sd, golden_dir):
     W = torch.randn(576, 576) * 0.05
     exact = A.double() @ W.double().T
     e_mfma = (engine_f32.debug_gemm_f32(A, W, mode=0)[0].double() - exact).abs()
-    for mode in (6, 9, 16, 17):
+    for mode in (16, 17):             # the engine's own f32x3 kernels: A split in registers / pre-split + LDS-DMA
         e_x3 = (engine_f32.debug_gemm_f32(A, W, mode=mode)[0].double() - exact).abs()
         assert float(e_x3.max()) <= 1.25 * float(e_mfma.max()) and float(e_x3.pow(2).mean()) <= 1.25 ** 2 * float(e_mfma.pow(2).mean())
     e3 = Engine(device=0, precision="f32x3")
@@ -1441,10 +1401,8 @@ def test_encoder_activations_beyond_4gib(engine, synth_sd, monkeypatch):
     assert torch.isfinite(big).all()
     exact = engine
     if engine.precision == "f32x3":
-        monkeypatch.setenv("MELLOW_SPLITK", "0")
-        exact = Engine(device=0, precision="f32x3")
+        exact = Engine(device=0, precision="f32x3", options={"splitk": 0})
         exact.load_state_dict(synth_sd)
-        monkeypatch.delenv("MELLOW_SPLITK")
         big_split, big = big, exact.encode(wav).cpu()
         assert float((big_split - big).abs().max()) <= 2e-5 * float(big.abs().max())
     try:

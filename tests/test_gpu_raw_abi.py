@@ -24,7 +24,7 @@ class Cfg(C.Structure):                      # mellow_config_t
 
 @pytest.mark.parametrize("host_rope", [True, False], ids=["rope_from_torch", "rope_in_library"])
 @pytest.mark.parametrize("precision", [0, 2, None], ids=["f32", "f32x3", "library_default"])
-def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope, precision):
+def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope, precision, monkeypatch):
     lib = C.CDLL(LIB)
     lib.mellow_last_error.restype = C.c_char_p
 
@@ -36,6 +36,9 @@ def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope,
     device = 0
     cfg = Cfg(2, 49152, 576, 1536, 30, 9, 3, 64, 1e-5, 100000.0, 2048, 129, 389, 0)
     h = C.c_void_p()
+    # (variables that switched kernels or numeric forms up to round 5: the round-6 library must ignore them)
+    for k, v in (("MELLOW_SPLITK", "0"), ("MELLOW_DECODE_X3", "0"), ("MELLOW_PREFILL_SPLIT", "1"), ("MELLOW_DECODE_FUSE", "0"), ("MELLOW_F32X3_TERMS", "9")):
+        monkeypatch.setenv(k, v)
     chk(lib.mellow_engine_create(C.byref(cfg), device, C.byref(h)))
     if precision is not None:                                               # no call: the library's default mode (f32x3)
         chk(lib.mellow_engine_set_precision(h, precision))                 # section 6
@@ -73,7 +76,26 @@ def test_raw_ctypes_binding_reproduces_the_reference_loop(golden_dir, host_rope,
     # the f32x3 modes because the engine measured that its side stream overlaps the main one -- not because of an import
     lib.mellow_prefill_parts.argtypes = [C.c_void_p]
     parts = lib.mellow_prefill_parts(h)
-    assert parts == (1 if precision == 0 else 2), parts
+    if precision == 0:
+        assert parts == 1, parts
+    elif parts != 2:        # a shared GPU may leave no free hardware queue while the probe runs: legal (one chain), but say so
+        import warnings
+        assert parts == 1, parts
+        warnings.warn("the engine's stream probe found no overlapping side stream on this box: the prefill ran as one chain")
+    # the library's configuration is explicit: with no mellow_engine_set_option call every option is at
+    # its default -- whatever MELLOW_* variables the process environment holds (the library reads none of them)
+    lib.mellow_engine_describe.restype = C.c_int64
+    lib.mellow_engine_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    n = lib.mellow_engine_describe(h, None, 0)
+    buf = C.create_string_buffer(n)
+    assert lib.mellow_engine_describe(h, buf, n) == n
+    import json
+    d = json.loads(buf.value.decode())
+    assert d["reads_environment"] is False and d["non_default"] == [] and d["finalized"] is True, d
+    assert d["precision"] == {None: "f32x3", 0: "f32", 2: "f32x3"}[precision] and d["abi"] == [2, lib.mellow_abi_minor()], d
+    assert all(o["value"] == o["default"] for o in d["options"].values()), d
+    lib.mellow_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    assert lib.mellow_engine_set_option(h, b"splitk", b"0") != 0 and b"before mellow_engine_finalize" in lib.mellow_last_error()
     lib.mellow_engine_destroy.argtypes = [C.c_void_p]
     lib.mellow_engine_destroy(h)
     assert steps.value == max_len and first_ms.value > 0

@@ -349,3 +349,31 @@ def test_non_finite_samples_are_sanitised_and_formats_reported(tmp_path):
     bad.write_bytes(b"ID3\x03\x00\x00\x00\x00\x00\x00not really audio")
     with pytest.raises(ValueError, match="cannot decode audio.*PCM / float WAV"):
         audio.load_wav(str(bad))
+
+
+def test_examples_signature_ignores_mtime_and_never_stats_the_prompt(tmp_path, monkeypatch):
+    """Data-parallel agreement (dist.examples_signature): two nodes holding COPIES of the same clips (same name and bytes, other
+    mtime) must agree; same-named files with other bytes must not; and the prompt slot is text only -- a prompt that happens to
+    name a file in one rank's working directory is the same prompt on every rank."""
+    import time
+    from mellow_amd import dist as mdist
+    a, b = tmp_path / "n0", tmp_path / "n1"
+    a.mkdir(); b.mkdir()
+    payload = (np.arange(200_000, dtype=np.int16)).tobytes()
+    for d in (a, b):
+        (d / "clip.wav").write_bytes(payload)
+    os.utime(b / "clip.wav", (time.time() - 86400, time.time() - 86400))          # the copy on "node 1" is a day older
+    sig = {}
+    for d in (a, b):
+        monkeypatch.chdir(d)
+        sig[d] = mdist.examples_signature([["clip.wav", "clip.wav", "what is this?"]])
+    assert sig[a] == sig[b]
+    (b / "clip.wav").write_bytes(payload[:-2] + b"\x01\x02")                      # same name and size, other tail bytes
+    monkeypatch.chdir(b)
+    assert mdist.examples_signature([["clip.wav", "clip.wav", "what is this?"]]) != sig[a]
+    # a prompt equal to an existing file's name: hashed as text on both ranks, whether or not the file exists there
+    monkeypatch.chdir(a)
+    (a / "notes.txt").write_bytes(b"x" * 10)
+    s_with = mdist.examples_signature([[np.zeros(4, np.float32), np.zeros(4, np.float32), "notes.txt"]])
+    monkeypatch.chdir(tmp_path)
+    assert mdist.examples_signature([[np.zeros(4, np.float32), np.zeros(4, np.float32), "notes.txt"]]) == s_with

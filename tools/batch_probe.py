@@ -2,10 +2,12 @@
 """Developer probe (GPU box): throughput and phase times of one generate() call at B = 32 / 64 / 128 (max_len 64,
 fixed-length), checking that the first 32 rows are bit-identical whatever the batch size."""
 import sys, time; sys.path.insert(0, ".")
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 import numpy as np
 from mellow_amd import synth
 from mellow_amd.engine import Engine
-eng = Engine(device=0, max_positions=1024); eng.load_state_dict(synth.make_state_dict(0))
+eng = Engine(device=0, max_positions=1024, options=OPTS); eng.load_state_dict(synth.make_state_dict(0))
 ref = None
 for B in (32, 64, 128):
     a1, a2, ids = synth.make_batch(B)

@@ -1,10 +1,12 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import synth
 from mellow_amd.engine import Engine
 sd = synth.make_state_dict(0)
 for prec in ("f32x3", "fp8"):
-    e = Engine(device=0, precision=prec)
+    e = Engine(device=0, precision=prec, options=OPTS)
     e.load_state_dict(sd)
     a1, a2, ids = synth.make_batch(32)
     t32, *_ = e.generate(a1, a2, ids, max_len=64, stop_id=0, ignore_stop=True)

@@ -7,10 +7,12 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import spec, synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
-eng = Engine(device=0, max_positions=1024)
+eng = Engine(device=0, max_positions=1024, options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
 for name, B, secs, L in (("C3 per-rank: B=32, 10 s, max_len 300", 32, 10, 300), ("C4: B=64, 30 s, max_len 128", 64, 30, 128)):
     a1, a2, ids = synth.make_batch(B, n_samples=secs * spec.SAMPLE_RATE)

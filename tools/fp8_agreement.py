@@ -10,15 +10,17 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
 STRUCT = len(sys.argv) > 1 and sys.argv[1] == "structured"
 sd = synth.make_state_dict(0, structured=STRUCT)
 print("checkpoint:", "structured (decaying singular spectrum)" if STRUCT else "default (i.i.d. Gaussian)")
-e32 = Engine(device=0, max_positions=1024)
+e32 = Engine(device=0, max_positions=1024, options=OPTS)
 e32.load_state_dict(sd)
-e8 = Engine(device=0, max_positions=1024, precision="fp8")
+e8 = Engine(device=0, max_positions=1024, precision="fp8", options=OPTS)
 e8.load_state_dict(sd)
 B, L = 32, 64
 a1, a2, ids = synth.make_batch(B)

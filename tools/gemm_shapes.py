@@ -8,12 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
-eng = Engine(device=0, precision=PREC)
+eng = Engine(device=0, precision=PREC, options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
 a1, a2, ids = synth.make_batch(B)
 a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)

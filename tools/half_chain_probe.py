@@ -6,12 +6,14 @@ could gain, without building it."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 import torch
 from mellow_amd import synth
 from mellow_amd.engine import Engine
 
 prec = os.environ.get("MELLOW_PRECISION", "f32x3")
-eng = Engine(device=0, precision=prec)
+eng = Engine(device=0, precision=prec, options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
 ctx = [eng.fork(), eng.fork()]
 a1, a2, ids = synth.make_batch(32)

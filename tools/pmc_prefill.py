@@ -4,9 +4,11 @@ mode (MELLOW_PRECISION, default f32x3)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import synth
 from mellow_amd.engine import Engine
-eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"))
+eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"), options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
 B = 32
 a1, a2, ids = synth.make_batch(B)

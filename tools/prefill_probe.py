@@ -5,10 +5,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _opts import engine_options  # noqa: E402  (--opt KEY=VALUE -> engine options)
+OPTS = engine_options()
 from mellow_amd import synth  # noqa: E402
 from mellow_amd.engine import Engine  # noqa: E402
 
-eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"))
+eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"), options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
 a1, a2, ids = synth.make_batch(32)
 a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
