@@ -122,6 +122,68 @@ __device__ __forceinline__ void apb_store_quads(i32x4* apb, int64_t m, int k8_ev
     apb_store8(apb, m, k8_even + h, KT, w);
 }
 
+// ---- "AMX": an activation matrix [M][K] as MXFP8 (e4m3 elements, one E8M0 scale per 32 consecutive k of a row) in the order the
+// LDS stage of gemm_mx8_kernel wants it (gemm_fp8.hip has the derivation of the operand order from the instruction) -------------
+// 16-byte slot of (row m, k64 step s, 32-block j of the step, 16-k half h of the block)
+__device__ __forceinline__ int64_t amx_slot(int64_t m, int s, int j, int h, int KT64) {
+    return (((((m >> 7) * KT64 + s) * 4 + ((m >> 5) & 3)) * 2 + j) * 64) + (m & 31) + 32 * h;
+}
+// byte address of the scale of (row m, block 2 s + j): word [panel][s / 4][m-tile][lane = m % 32 + 32 j], byte s % 4
+__device__ __forceinline__ int64_t amx_scale_byte(int64_t m, int s, int j, int KQ) {
+    return (((((m >> 7) * KQ + (s >> 2)) * 4 + ((m >> 5) & 3)) * 64) + (m & 31) + 32 * j) * 4 + (s & 3);
+}
+// biased exponent e of the block scale 2^(e - 127) = the smallest power of two with amax / scale <= 448 (no element clips);
+// an all-zero block takes 2^0.  inverse = 2^(127 - e) exactly.
+__device__ __forceinline__ int mx8_exponent(float amax) {
+    const uint32_t b = __float_as_uint(amax * (1.0f / 448.0f));
+    int e = (int)((b >> 23) & 0xFF) + ((b & 0x7FFFFF) ? 1 : 0);
+    e = e < 1 ? 1 : (e > 253 ? 253 : e);
+    return amax > 0.f ? e : 127;
+}
+__device__ __forceinline__ float mx8_inverse(int e) { return __uint_as_float((uint32_t)(254 - e) << 23); }
+__device__ __forceinline__ int mx8_pack4(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+// The MFMA epilogues (and the attention epilogues) hold one 32-column block of a row in a lane PAIR: lane (row, h = lane / 32) owns
+// columns 8 g + 4 h + (0..3), g = 0..3, as v[4 g .. 4 g + 3].  Block scale from both lanes' values, quantise, then two dword-level
+// v_permlane32_swap give the lower lane columns 0..15 and the upper lane columns 16..31: each stores one whole 16-byte slot.
+__device__ __forceinline__ void amx_store_block(i32x4* img, uint8_t* sc, int64_t m, int kb, int KT64, int KQ, const float (&v)[16], int h) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = half_max(amax);
+    const int e = mx8_exponent(amax);
+    const float inv = mx8_inverse(e);
+    int w[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g] = mx8_pack4(v[4 * g] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
+    // lower lane: (own g0, partner g0, own g1, partner g1) = columns 0..15; upper lane: (partner g2, own g2, partner g3, own g3) = 16..31
+    auto r0 = __builtin_amdgcn_permlane32_swap((uint32_t)w[0], (uint32_t)w[2], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap((uint32_t)w[1], (uint32_t)w[3], false, false);
+    const int s = kb >> 1, j = kb & 1;
+    img[amx_slot(m, s, j, h, KT64)] = i32x4{(int)r0[0], (int)r0[1], (int)r1[0], (int)r1[1]};
+    if (h == 0) sc[amx_scale_byte(m, s, j, KQ)] = (uint8_t)e;
+}
+
+// the same for a lane that already holds 16 CONSECUTIVE columns of its row: y = columns 32 kb + 16 h .. + 15 (norm kernels, quantiser)
+__device__ __forceinline__ void amx_store16(i32x4* img, uint8_t* sc, int64_t m, int kb, int KT64, int KQ, const float (&y)[16], int h) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(y[i]));
+    amax = half_max(amax);
+    const int e = mx8_exponent(amax);
+    const float inv = mx8_inverse(e);
+    i32x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = mx8_pack4(y[4 * q] * inv, y[4 * q + 1] * inv, y[4 * q + 2] * inv, y[4 * q + 3] * inv);
+    const int s = kb >> 1, j = kb & 1;
+    img[amx_slot(m, s, j, h, KT64)] = w;
+    if (h == 0) sc[amx_scale_byte(m, s, j, KQ)] = (uint8_t)e;
+}
+
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): logical ids that are consecutive land on
 // the same XCD so tiles sharing an operand panel hit one L2.  Bijective for any block count.
 __device__ __forceinline__ int xcd_remap(int b, int nb) {

@@ -224,10 +224,13 @@ void launch_merge_layernorm(const float* in, float* out, int n, int R, int C, co
 // a workgroup owns 32 consecutive OUTPUT rows: pass 1 gathers them (one row per wave at a time, coalesced), keeps them in LDS
 // and forms mean / rstd; pass 2 re-reads them from LDS in the (row % 32, k-half) order of an APB slot run, so that every store
 // instruction of a wave writes 1 KiB contiguous (the scheme of rmsnorm_apb_kernel below).  NQ = float4 per lane (C <= 256 NQ).
-template <int NQ>
+// AMX = true (fp8 mode): the same rows, quantised to MXFP8 in the AMX image order of gemm_mx8_kernel (common.h: one scale per 32
+// columns; a lane of pass 2 holds 16 consecutive columns, its partner lane the other 16 of the block; pad blocks up to a whole
+// k64 step are written as zeros).
+template <int NQ, bool AMX>
 __global__ __launch_bounds__(256) void layernorm_apb_kernel(const float* __restrict__ in, i32x4* __restrict__ out, int64_t M, int C,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            const int32_t* __restrict__ row_map, int ntok) {
+                                                            const int32_t* __restrict__ row_map, int ntok, uint8_t* __restrict__ sc) {
     extern __shared__ __attribute__((aligned(16))) float ln_rows_s[];
     __shared__ float mu_s[32], rs_s[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,6 +282,28 @@ __global__ __launch_bounds__(256) void layernorm_apb_kernel(const float* __restr
     if (m >= M) return;
     const float mean = mu_s[ml], rstd = rs_s[ml];
     const int kh = lane >> 5;
+    if constexpr (AMX) {
+        const int KT64 = (C + 63) >> 6, KQ = (KT64 + 3) >> 2;
+        for (int kb = wave; kb < 2 * KT64; kb += 4) {
+            const int col = kb * 32 + kh * 16;
+            float y[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col + 4 * q < C) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(ln_rows_s + ml * RS + col + 4 * q);
+                    const float4 w0 = *reinterpret_cast<const float4*>(w + col + 4 * q), b0 = *reinterpret_cast<const float4*>(b + col + 4 * q);
+                    v.x = (x0.x - mean) * rstd * w0.x + b0.x;
+                    v.y = (x0.y - mean) * rstd * w0.y + b0.y;
+                    v.z = (x0.z - mean) * rstd * w0.z + b0.z;
+                    v.w = (x0.w - mean) * rstd * w0.w + b0.w;
+                }
+                y[4 * q] = v.x; y[4 * q + 1] = v.y; y[4 * q + 2] = v.z; y[4 * q + 3] = v.w;
+            }
+            amx_store16(out, sc, m, kb, KT64, KQ, y, kh);
+        }
+        return;
+    }
     for (int kt = wave; kt < KT; kt += 4) {
         const int col = kt * 16 + kh * 8;
         const float4 x0 = *reinterpret_cast<const float4*>(ln_rows_s + ml * RS + col), x1 = *reinterpret_cast<const float4*>(ln_rows_s + ml * RS + col + 4);
@@ -298,16 +323,22 @@ __global__ __launch_bounds__(256) void layernorm_apb_kernel(const float* __restr
 }
 // C % 16 == 0, C <= 768; out_apb holds roundup(M, 128) rows (rows >= M are left as they are: their products are never stored)
 void launch_layernorm_apb(const float* in, void* out_apb, int M, int C, const float* w, const float* b, const int32_t* row_map,
-                          int ntok, hipStream_t s) {
+                          int ntok, hipStream_t s, void* out_scales) {
     const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 98.8 KB at C = 768
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<1>), 100 * 1024);       // per (function, device)
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<2>), 100 * 1024);
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<3>), 100 * 1024);
     const dim3 grid((M + 31) / 32), block(256);
     i32x4* o = reinterpret_cast<i32x4*>(out_apb);
-    if (C <= 256) hipLaunchKernelGGL((layernorm_apb_kernel<1>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
-    else if (C <= 512) hipLaunchKernelGGL((layernorm_apb_kernel<2>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
-    else hipLaunchKernelGGL((layernorm_apb_kernel<3>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(out_scales);
+#define MELLOW_LN_LAUNCH(NQ, AMX)                                                                                        \
+    do {                                                                                                                 \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&layernorm_apb_kernel<NQ, AMX>), 100 * 1024);                  \
+        hipLaunchKernelGGL((layernorm_apb_kernel<NQ, AMX>), grid, block, lds, s, in, o, (int64_t)M, C, w, b, row_map, ntok, sc); \
+    } while (0)
+    if (out_scales) {        // AMX image + scale bytes (fp8 mode)
+        if (C <= 256) MELLOW_LN_LAUNCH(1, true); else if (C <= 512) MELLOW_LN_LAUNCH(2, true); else MELLOW_LN_LAUNCH(3, true);
+    } else {
+        if (C <= 256) MELLOW_LN_LAUNCH(1, false); else if (C <= 512) MELLOW_LN_LAUNCH(2, false); else MELLOW_LN_LAUNCH(3, false);
+    }
+#undef MELLOW_LN_LAUNCH
 }
 
 // LlamaRMSNorm (fp32): w * (x * rsqrt(mean(x^2) + eps))
@@ -350,8 +381,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // re-reads the rows (L2-hot) with lane = (row % 32, k-half), the order of an APB slot run, so every store instruction of a
 // wave writes 1 KiB contiguous (a first version that stored from the row-per-wave mapping scattered 16-byte pieces 12 KiB
 // apart and took 2.3x the time of the plain kernel)
+template <bool AMX>
 __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restrict__ in, i32x4* __restrict__ out, int64_t M,
-                                                          int C, const float* __restrict__ w, float eps) {
+                                                          int C, const float* __restrict__ w, float eps, uint8_t* __restrict__ sc) {
     // The 32 rows of the workgroup are staged in LDS by pass 1 (coalesced row reads) and re-read from there by pass 2 in the
     // (row % 32, k-half) order of an APB slot run: a second pass over global memory in that order touches 32 cache lines per load
     // instruction (22 us per launch at M = 12448; from LDS: see profiles/).  Row stride C + 4 floats: the sixteen lanes of a
@@ -391,6 +423,26 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
     if (m >= M) return;
     const float r = rs[ml];
     const int kh = lane >> 5;
+    if constexpr (AMX) {          // fp8 mode: the same values as MXFP8 in AMX order (see layernorm_apb_kernel)
+        const int KT64 = (C + 63) >> 6, KQ = (KT64 + 3) >> 2;
+        for (int kb = wave; kb < 2 * KT64; kb += 4) {
+            const int col = kb * 32 + kh * 16;
+            float y[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col + 4 * q < C) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(rows_s + ml * RS + col + 4 * q);
+                    const float4 w0 = *reinterpret_cast<const float4*>(w + col + 4 * q);
+                    v = make_float4(__fmul_rn(w0.x, __fmul_rn(x0.x, r)), __fmul_rn(w0.y, __fmul_rn(x0.y, r)), __fmul_rn(w0.z, __fmul_rn(x0.z, r)),
+                                    __fmul_rn(w0.w, __fmul_rn(x0.w, r)));
+                }
+                y[4 * q] = v.x; y[4 * q + 1] = v.y; y[4 * q + 2] = v.z; y[4 * q + 3] = v.w;
+            }
+            amx_store16(out, sc, m, kb, KT64, KQ, y, kh);
+        }
+        return;
+    }
     for (int kt = wave; kt < KT; kt += 4) {
         const int col = kt * 16 + kh * 8;
         const float4 x0 = *reinterpret_cast<const float4*>(rows_s + ml * RS + col), x1 = *reinterpret_cast<const float4*>(rows_s + ml * RS + col + 4);
@@ -401,10 +453,12 @@ __global__ __launch_bounds__(256) void rmsnorm_apb_kernel(const float* __restric
         apb_store8(out, m, kt * 2 + kh, KT, y);
     }
 }
-void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s) {
+void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s, void* out_scales) {
     const size_t lds = (size_t)32 * (C + 4) * sizeof(float);          // 74 KB at C = 576: two workgroups per CU
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&rmsnorm_apb_kernel), 96 * 1024);
-    hipLaunchKernelGGL(rmsnorm_apb_kernel, dim3((M + 31) / 32), dim3(256), lds, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&rmsnorm_apb_kernel<false>), 96 * 1024);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&rmsnorm_apb_kernel<true>), 96 * 1024);
+    if (out_scales) hipLaunchKernelGGL(rmsnorm_apb_kernel<true>, dim3((M + 31) / 32), dim3(256), lds, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps, reinterpret_cast<uint8_t*>(out_scales));
+    else hipLaunchKernelGGL(rmsnorm_apb_kernel<false>, dim3((M + 31) / 32), dim3(256), lds, s, in, reinterpret_cast<i32x4*>(out_apb), (int64_t)M, C, w, eps, (uint8_t*)nullptr);
 }
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, out, (int64_t)M, C, w, eps);

@@ -499,7 +499,7 @@ int mellow_stft_is_fft(mellow_engine_t* e) { return e && e->fft_win ? 1 : 0; }
 int mellow_abi_minor(void) { return MELLOW_ABI_MINOR; }
 int mellow_prefill_parts(mellow_engine_t* e) {
     if (!e) return -1;
-    if (!e->f32x3_terms) return 1;             // only the f32x3 prefill splits
+    if (!e->f32x3_terms && !(e->fp8 && e->fp8_prefill)) return 1;             // only the f32x3 / fp8 prefills (producers hand over in operand format) split
     if (hipSetDevice(e->device) != hipSuccess) return -1;
     if (ensure_prefill_streams(e) != 0) return -1;
     return e->prefill_parts < 1 ? 1 : (e->prefill_parts > 4 ? 4 : e->prefill_parts);

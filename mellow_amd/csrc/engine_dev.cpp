@@ -94,28 +94,28 @@ int mellow_debug_gemm_f32(mellow_engine_t* e, int mode, const float* A, int M, i
 // plain epilogue) and, optionally, its average time: the quantisation parity tap of include/mellow_hip.h
 int mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, const float* W, int N, float* C_out, int iters,
                         float* ms_out) {
-    if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 4) return fail("bad argument");
+    if (!e || !A || !W || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
-    const int NP = rup(N, 128);
+    const int NP = rup(N, 128), K64 = rup(K, 64), Mp = rup(M, 128);
     float *dA = nullptr, *dW = nullptr, *dWp = nullptr, *dC = nullptr, *dsa = nullptr, *dsw = nullptr;
     uint8_t *dA8 = nullptr, *dW8 = nullptr;
     HIPCHK(hipMalloc(&dA, (size_t)M * K * 4));
     HIPCHK(hipMalloc(&dW, (size_t)N * K * 4));
     HIPCHK(hipMalloc(&dWp, (size_t)NP * K * 4));
     HIPCHK(hipMalloc(&dC, (size_t)M * N * 4));
-    HIPCHK(hipMalloc(&dsa, (size_t)M * 4));
+    HIPCHK(hipMalloc(&dsa, (size_t)Mp * ((K64 / 64 + 3) / 4) * 8));       // 2 scale words per row and four k64 steps
     HIPCHK(hipMalloc(&dsw, (size_t)NP * 4));
-    HIPCHK(hipMalloc(&dA8, (size_t)M * K));
-    HIPCHK(hipMalloc(&dW8, (size_t)NP * K));
+    HIPCHK(hipMalloc(&dA8, (size_t)Mp * K64));
+    HIPCHK(hipMalloc(&dW8, (size_t)NP * K64));
     HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dW, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
     launch_pack_weight(dW, N, K, K, dWp, NP, K, s);
     launch_pack_fp8(dWp, NP, K, dW8, dsw, s);
     GemmArgs g;
     g.A = dA; g.lda = K; g.M = M; g.K = K; g.Wp = dWp; g.Nw = N; g.N = N; g.C = dC; g.ldc = N;
-    g.A8 = dA8; g.lda8 = K; g.a_scale = dsa; g.W8 = dW8; g.w_scale = dsw;
-    launch_quant_rows(dA, K, M, K, dA8, K, dsa, s);
+    g.A8 = dA8; g.lda8 = K64; g.a_sc = reinterpret_cast<const uint32_t*>(dsa); g.W8 = dW8; g.w_scale = dsw;
+    launch_quant_mx8(dA, K, M, K, dA8, dsa, s);
     launch_gemm_fp8(g, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
@@ -126,7 +126,7 @@ int mellow_debug_gemm_fp8(mellow_engine_t* e, const float* A, int M, int K, cons
         HIPCHK(hipEventCreate(&b));
         float ms_q = 0.f, ms_g = 0.f;
         HIPCHK(hipEventRecord(a, s));
-        for (int i = 0; i < iters; ++i) launch_quant_rows(dA, K, M, K, dA8, K, dsa, s);
+        for (int i = 0; i < iters; ++i) launch_quant_mx8(dA, K, M, K, dA8, dsa, s);
         HIPCHK(hipEventRecord(b, s));
         HIPCHK(hipEventSynchronize(b));
         HIPCHK(hipEventElapsedTime(&ms_q, a, b));

@@ -33,16 +33,17 @@ int run_gemm(mellow_engine* e, const GemmArgs& a) {
     if (e->fp8 && e->fp8_prefill && a.a_mode == A_PLAIN && (a.epi == EPI_LINEAR || a.epi == EPI_SWIGLU || a.epi == EPI_QKV_ROPE)) {
         auto it = e->fp8_w.find(a.Wp);
         if (it != e->fp8_w.end()) {
-            // quantise the activation rows, then the fp8 MFMA GEMM (same epilogue); profiled as one launch of the family
-            const int64_t lda8 = (a.K + 63) / 64 * 64;
-            CHK(ensure(e, e->a8, ((size_t)a.M * lda8 + 3) / 4));
-            CHK(ensure(e, e->a8_scale, (size_t)a.M));
+            // no producer handed this input over quantised: the standalone fp32 -> AMX pass, then the MX GEMM (same epilogue);
+            // profiled as one launch of the family
+            const int64_t lda8 = (a.K + 63) / 64 * 64, Mp = rup(a.M, 128);
+            CHK(ensure(e, e->a8, ((size_t)Mp * lda8 + 3) / 4));
+            CHK(ensure(e, e->a8_scale, (size_t)Mp * ((lda8 / 64 + 3) / 4) * 2));      // 2 scale words per row and four k64 steps
             GemmArgs g = a;
-            g.A8 = reinterpret_cast<const uint8_t*>(e->a8.p); g.lda8 = lda8; g.a_scale = e->a8_scale.p;
+            g.A8 = reinterpret_cast<const uint8_t*>(e->a8.p); g.lda8 = lda8; g.a_sc = reinterpret_cast<const uint32_t*>(e->a8_scale.p);
             g.W8 = it->second.w8; g.w_scale = it->second.scale;
             ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
             ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 100;
-            launch_quant_rows(a.A, a.lda, a.M, a.K, reinterpret_cast<uint8_t*>(e->a8.p), lda8, e->a8_scale.p, e->stream);
+            launch_quant_mx8(a.A, a.lda, a.M, a.K, e->a8.p, e->a8_scale.p, e->stream);
             launch_gemm_fp8(g, e->stream);
             return 0;
         }
@@ -52,13 +53,25 @@ int run_gemm(mellow_engine* e, const GemmArgs& a) {
     launch_gemm(a, e->stream);
     return 0;
 }
-// f32x3 mode, LM prefill: the activation arrives pre-split in APB order from its producer (a3) and both operands are staged
-// by LDS-DMA (gemm_x3q_kernel); counted in the same profile family as every other dense GEMM
-int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_t st) {
-    auto it = e->bf_w.find(a.Wp);
-    if (it == e->bf_w.end()) return fail("internal: no bf16-split copy of this weight");
+// The activation arrives from its PRODUCER already in the GEMM's operand format and LDS order, and both operands are staged by
+// LDS-DMA; counted in the same profile family as every other dense GEMM.
+//   f32x3 mode: a3 = APB image (three bf16 pieces, common.h) -> gemm_x3q_kernel
+//   fp8 mode:   a3 = AMX image (MXFP8) + a3_scales (its scale bytes) -> gemm_mx8_kernel
+int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_t st, const void* a3_scales) {
     GemmArgs g = a;
     g.A8 = reinterpret_cast<const uint8_t*>(a3);
+    if (a3_scales) {
+        auto it = e->fp8_w.find(a.Wp);
+        if (it == e->fp8_w.end()) return fail("internal: no e4m3 copy of this weight");
+        g.a_sc = reinterpret_cast<const uint32_t*>(a3_scales); g.lda8 = rup(a.K, 64);
+        g.W8 = it->second.w8; g.w_scale = it->second.scale;
+        ProfScope ps(e, PF_GEMM, gemm_flops(a), 0.0);
+        ps.r.M = a.M; ps.r.N = a.Nw; ps.r.K = a.K; ps.r.epi = a.epi + 500;
+        launch_gemm_fp8(g, st ? st : e->stream);
+        return 0;
+    }
+    auto it = e->bf_w.find(a.Wp);
+    if (it == e->bf_w.end()) return fail("internal: no bf16-split copy of this weight");
     g.W8 = reinterpret_cast<const uint8_t*>(it->second);
     if (!st || st == e->stream) with_splitk(e, g);
     g.no_x3w = !e->x3w;
@@ -153,21 +166,31 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
             // order and qkv / fc1 / fc2 run on the LDS-DMA kernel (gemm_x3q_kernel); H never exists as fp32
             // bit 8 + st: only the LayerNorms hand over pre-split (qkv and fc1 on the APB kernels, fc1 still writes fp32): stage 0,
             // whose K = 96 GEMMs then run on the weight-stationary persistent kernel (gemm_x3w_kernel)
+            // fp8 mode (`amx`), every stage: the same hand-over with AMX images (MXFP8, common.h) -- the LayerNorms and the GELU
+            // epilogue of fc1 emit e4m3 + block scales in the consumer's LDS order, qkv / fc1 / fc2 run on gemm_mx8_kernel straight
+            // from them (K = 96 zero-padded to two k64 steps); the window attention still writes fp32 (head_dim 24 does not tile 32-
+            // column blocks) and the proj GEMM takes the standalone quantiser
+            const bool amx = e->fp8 && e->fp8_prefill && e->x3_apb && e->fp8_w.count(w.qkv.p) && e->fp8_w.count(w.fc1.p) && e->fp8_w.count(w.fc2.p);
             const bool have_pb = e->f32x3_terms && e->bf_w.count(w.qkv.p) && e->bf_w.count(w.fc1.p) && e->bf_w.count(w.fc2.p);
-            const bool apb_h = have_pb && ((e->enc_apb_stages >> st) & 1);
+            const bool apb_h = amx || (have_pb && ((e->enc_apb_stages >> st) & 1));
             const bool apb = apb_h || (have_pb && ((e->enc_apb_stages >> (8 + st)) & 1));
             const size_t M1p = (size_t)rup(M1, 128);
+            char *a3s = nullptr, *h3s = nullptr;          // fp8 mode: scale bytes behind the image data, in the same buffers
             if (apb) {
                 CHK(ensure(e, e->enc_a3, (M1p * C * 6 + 3) / 4));
                 if (apb_h) CHK(ensure(e, e->enc_h3, (M1p * 4 * C * 6 + 3) / 4));
-                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n1w, w.n1b, map, N, s); }
-                CHK(run_gemm_apb(e, lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b), e->enc_a3.p, s));
+                if (amx) {
+                    a3s = reinterpret_cast<char*>(e->enc_a3.p) + M1p * rup(C, 64);
+                    h3s = reinterpret_cast<char*>(e->enc_h3.p) + M1p * rup(4 * C, 64);
+                }
+                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n1w, w.n1b, map, N, s, a3s); }
+                CHK(run_gemm_apb(e, lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b), e->enc_a3.p, s, a3s));
             } else {
                 { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n1w, w.n1b, map, N, s); }
                 CHK(run_gemm(e, lin(t, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b)));
             }
             // bits 4..7 of enc_apb_stages: the window attention hands its output over pre-split too (proj on the x3q kernel)
-            const bool apb_proj = apb && ((e->enc_apb_stages >> (4 + st)) & 1) && e->bf_w.count(w.proj.p);
+            const bool apb_proj = apb && !amx && ((e->enc_apb_stages >> (4 + st)) & 1) && e->bf_w.count(w.proj.p);
             {
                 ProfScope ps(e, PF_WINDOW_ATTN, 4.0 * 64 * 64 * 24 * (double)(M1 / 64) * nH, 4.0 * M1 * C * 4);
                 launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s, apb_proj ? e->enc_a3.p : nullptr);
@@ -179,16 +202,17 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
                 else CHK(run_gemm(e, g));
             }
             if (apb) {
-                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n2w, w.n2b, nullptr, N, s); }
+                { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n2w, w.n2b, nullptr, N, s, a3s); }
                 {
                     GemmArgs g = lin(nullptr, C, M1, w.fc1, apb_h ? nullptr : e->H.p, 4 * C, w.fc1_b);
                     g.act = ACT_GELU; g.C3 = apb_h ? e->enc_h3.p : nullptr;
-                    CHK(run_gemm_apb(e, g, e->enc_a3.p, s));
+                    if (amx) { g.c3_fmt = 1; g.C3s = reinterpret_cast<uint8_t*>(h3s); g.c3_kt64 = rup(4 * C, 64) / 64; }
+                    CHK(run_gemm_apb(e, g, e->enc_a3.p, s, a3s));
                 }
                 {
                     GemmArgs g = lin(apb_h ? nullptr : e->H.p, 4 * C, M1, w.fc2, x, C, w.fc2_b);
                     g.resid = x; g.ldr = C;
-                    if (apb_h) CHK(run_gemm_apb(e, g, e->enc_h3.p, s));
+                    if (apb_h) CHK(run_gemm_apb(e, g, e->enc_h3.p, s, h3s));
                     else CHK(run_gemm(e, g));
                 }
             } else {

@@ -274,7 +274,7 @@ struct ProfScope {
 };
 // engine_encoder.cpp
 int run_gemm(mellow_engine* e, const GemmArgs& a);
-int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_t st = nullptr);
+int run_gemm_apb(mellow_engine* e, const GemmArgs& a, const void* a3, hipStream_t st = nullptr, const void* a3_scales = nullptr);
 GemmArgs lin(const float* A, int64_t lda, int M, const Packed& w, float* C, int64_t ldc, const float* bias);
 int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, int want_logmel_only, int apply_bn, float* logmel_out);
 // engine_lm.cpp

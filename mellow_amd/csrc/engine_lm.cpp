@@ -13,7 +13,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
     CHK(ensure(e, e->lm_q, Mp * 576));
     CHK(ensure(e, e->lm_o, Mp * 576));
     CHK(ensure(e, e->lm_h, Mp * 1536));
-    if (e->f32x3_terms) {                       // 6 bytes per element, rows padded to whole 128-row panels
+    if (e->f32x3_terms || (e->fp8 && e->fp8_prefill)) {      // 6 bytes per element (the fp8 mode's AMX images + scale bytes need 1.05), rows padded to whole 128-row panels
         const size_t Mq = (size_t)rup((int)Mp, 128) + 3 * 128;   // + three panels: every part of the split prefill starts on a panel boundary
         CHK(ensure(e, e->lm_xn3, Mq * 576 * 6 / 4));
         CHK(ensure(e, e->lm_o3, Mq * 576 * 6 / 4));
@@ -142,7 +142,10 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
     const int M = B * T, Tmax = e->kv_Tmax;
     const int NL = e->cfg.num_layers;
     float *x = e->lm_x.p, *xn = e->lm_xn.p;
-    const bool apb = e->f32x3_terms && e->x3_apb;        // option "x3_apb" = 0: the register-staged x3p kernel (developer A/B)
+    // fp8 mode: the same producer -> consumer hand-over with AMX images (MXFP8, common.h) instead of APB ones: `amx`; the code below
+    // says `apb` for "GEMM inputs leave their producers in operand format"
+    const bool amx = e->fp8 && e->fp8_prefill && e->x3_apb && e->fp8_w.count(e->layers[0].qkv.p) != 0;
+    const bool apb = (e->f32x3_terms && e->x3_apb) || amx;        // option "x3_apb" = 0: the register-staged x3p kernel / the standalone quantiser (developer A/B)
     // Split prefill (f32x3 mode): the batch is cut into independent parts (2 by default) that run the same launches on their own
     // streams, so the tails and the fill / drain of one part's kernels are covered by another's (every buffer is indexed by row
     // or by example, so a part is an offset; its pre-split operands get their own panel-aligned region).  Measured before it was
@@ -197,6 +200,12 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
             char* xn3 = apb ? reinterpret_cast<char*>(e->lm_xn3.p) + prow[h] * 576 * 6 : nullptr;
             char* o3 = apb ? reinterpret_cast<char*>(e->lm_o3.p) + prow[h] * 576 * 6 : nullptr;
             char* h3 = apb ? reinterpret_cast<char*>(e->lm_h3.p) + prow[h] * 1536 * 6 : nullptr;
+            // fp8 mode: the same regions hold [AMX data: rows x K bytes | scale bytes: rows x ceil(K / 256) x 8]; rows of this part
+            char *xn3s = nullptr, *o3s = nullptr, *h3s = nullptr;
+            if (amx) {
+                xn3s = xn3 + (size_t)rup(Mh, 128) * 576; o3s = o3 + (size_t)rup(Mh, 128) * 576; h3s = h3 + (size_t)rup(Mh, 128) * 1536;
+            }
+            auto c3_amx = [&](GemmArgs& g, char* scales, int kt64) { if (amx) { g.c3_fmt = 1; g.C3s = reinterpret_cast<uint8_t*>(scales); g.c3_kt64 = kt64; } };
             // norm-free chaining (fz): the residual stream leaves the o_proj / down GEMMs already pre-split together with its
             // sum-of-squares partials (ssq_mid after o_proj, ssq_in after down); the GEMM that follows runs on the norm-folded
             // weight and applies the row statistic to its accumulators -- 59 of the 60 normalisation launches of a prefill disappear
@@ -210,7 +219,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
             // order the GEMM's LDS stage wants it (APB, common.h), and the GEMM stages both operands by LDS-DMA (x3q)
             const bool fz_in = fz && l > 0;       // this layer's input came out of the previous layer's down GEMM pre-split
             if (fz_in) {}
-            else if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.in_ln, e->cfg.rms_norm_eps, st); }
+            else if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.in_ln, e->cfg.rms_norm_eps, st, xn3s); }
             else { ProfScope ps(e, PF_NORM, 0, 2.0 * Mh * 576 * 4); launch_rmsnorm(xh, xnh, Mh, 576, w.in_ln, e->cfg.rms_norm_eps, st); }
             {
                 GemmArgs g;
@@ -218,7 +227,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
                 if (fz_in) with_rs(g, ssq_in);
                 g.q_out = qh; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
                 g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
-                if (apb) CHK(run_gemm_apb(e, g, xn3, st)); else CHK(run_gemm(e, g));
+                if (apb) CHK(run_gemm_apb(e, g, xn3, st, xn3s)); else CHK(run_gemm(e, g));
             }
             // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
             // outputs; their K/V pages were just written above): it is finished below by the decode kernels on B rows.
@@ -227,29 +236,29 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
                 // causal QK^T + PV: 4*64 flops per (query,key) pair per head
                 ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)Bh * ((double)T * (T + 1) / 2), 0);
                 const bool attn_f32 = !e->x3_attn;   // option "x3_attn" = 0: f32x3 mode on the fp32 kernel (A/B)
-                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, e->f32x3_terms != 0 && !attn_f32, st);
+                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, (e->f32x3_terms != 0 || amx) && !attn_f32, st, o3s);
             }
             {
                 GemmArgs g = lin(oh, 576, Mh, w.o, xh, 576, nullptr);
                 g.resid = xh; g.ldr = 576;
-                if (fz) { g.C3 = xn3; g.ssq_out = ssq_mid; g.ssq_parts = 9; }
-                if (apb) CHK(run_gemm_apb(e, g, o3, st)); else CHK(run_gemm(e, g));
+                if (fz) { g.C3 = xn3; g.ssq_out = ssq_mid; g.ssq_parts = 9; c3_amx(g, xn3s, 9); }
+                if (apb) CHK(run_gemm_apb(e, g, o3, st, o3s)); else CHK(run_gemm(e, g));
             }
             if (fz) {}
-            else if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.post_ln, e->cfg.rms_norm_eps, st); }
+            else if (apb) { ProfScope ps(e, PF_NORM, 0, 2.5 * Mh * 576 * 4); launch_rmsnorm_apb(xh, xn3, Mh, 576, w.post_ln, e->cfg.rms_norm_eps, st, xn3s); }
             else { ProfScope ps(e, PF_NORM, 0, 2.0 * Mh * 576 * 4); launch_rmsnorm(xh, xnh, Mh, 576, w.post_ln, e->cfg.rms_norm_eps, st); }
             {
                 GemmArgs g;
                 g.A = xnh; g.lda = 576; g.M = Mh; g.K = 576; g.Wp = fz ? w.gateup_f.p : w.gateup.p; g.Nw = 3072; g.N = 1536; g.C = hh; g.ldc = 1536;
                 g.epi = EPI_SWIGLU;
                 if (fz) with_rs(g, ssq_mid);
-                if (apb) { g.C3 = h3; CHK(run_gemm_apb(e, g, xn3, st)); } else CHK(run_gemm(e, g));
+                if (apb) { g.C3 = h3; c3_amx(g, h3s, 24); CHK(run_gemm_apb(e, g, xn3, st, xn3s)); } else CHK(run_gemm(e, g));
             }
             {
                 GemmArgs g = lin(hh, 1536, Mh, w.down, xh, 576, nullptr);
                 g.resid = xh; g.ldr = 576;
-                if (fz) { g.C3 = xn3; g.ssq_out = ssq_in; g.ssq_parts = 9; }
-                if (apb) CHK(run_gemm_apb(e, g, h3, st)); else CHK(run_gemm(e, g));
+                if (fz) { g.C3 = xn3; g.ssq_out = ssq_in; g.ssq_parts = 9; c3_amx(g, xn3s, 9); }
+                if (apb) CHK(run_gemm_apb(e, g, h3, st, h3s)); else CHK(run_gemm(e, g));
             }
         }
         if (last) break;

@@ -56,9 +56,9 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
         HIPCHK(hipStreamSynchronize(e->stream));
         e->bf_w[p.p] = pb;
     }
-    if (e->fp8 && p.KP % 64 == 0 && !e->decode_only_weight) {
+    if (e->fp8 && e->fp8_prefill && !e->decode_only_weight) {       // WMX image: K zero-padded to whole k64 steps (K = 96 -> 128)
         float *w8f = nullptr, *sc = nullptr;
-        CHK(dev_alloc(e, &w8f, ((size_t)p.NP * p.KP + 3) / 4));
+        CHK(dev_alloc(e, &w8f, ((size_t)p.NP * rup(p.KP, 64) + 3) / 4));
         CHK(dev_alloc(e, &sc, (size_t)p.NP));
         launch_pack_fp8(p.p, p.NP, p.KP, reinterpret_cast<uint8_t*>(w8f), sc, e->stream);
         HIPCHK(hipGetLastError());
@@ -66,6 +66,18 @@ static int make_packed(mellow_engine* e, const float* w0, const float* w1, int N
         e->fp8_w[p.p] = {reinterpret_cast<uint8_t*>(w8f), sc};
     }
     *out = p;
+    return 0;
+}
+// e4m3 (WMX) copy of an already packed weight: the operand of gemm_mx8_kernel (fp8 mode)
+static int make_w8(mellow_engine* e, const Packed& p) {
+    if (!e->fp8 || !e->fp8_prefill || e->fp8_w.count(p.p)) return 0;
+    float *w8f = nullptr, *sc = nullptr;
+    CHK(dev_alloc(e, &w8f, ((size_t)p.NP * rup(p.KP, 64) + 3) / 4));
+    CHK(dev_alloc(e, &sc, (size_t)p.NP));
+    launch_pack_fp8(p.p, p.NP, p.KP, reinterpret_cast<uint8_t*>(w8f), sc, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->fp8_w[p.p] = {reinterpret_cast<uint8_t*>(w8f), sc};
     return 0;
 }
 // bf16-split (PB) copy of an already packed weight: the operand of the x3q GEMM (f32x3 mode)
@@ -122,7 +134,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
         CHK(make_packed(e, get(e, kr)->f(), get(e, ki)->f(), kNfreq, kNfft, &e->dft));
         // MELLOW_STFT_FFT=0: the DFT GEMM on the split kernel; MELLOW_X3_STFT=0: the whole front-end on the exact fp32 kernel
         const bool no_fft = !e->stft_fft;            // options "stft_fft" / "x3_stft"
-        if (e->f32x3_terms && !no_fft && kNfft == 1024) {
+        if ((e->f32x3_terms || (e->fp8 && e->fp8_prefill)) && !no_fft && kNfft == 1024) {       // (fp8 mode: the front-end stays fp32 arithmetic; the FFT is that)
             // the reference builds these weights as window[n] * cos / -sin(2 pi k n / N) (torchlibrosa STFT, frozen parameters);
             // a checkpoint that holds anything else keeps the GEMM.  Row k = 0 of the real part IS the window.
             const float *wr = get(e, kr)->f(), *wi = get(e, ki)->f();
@@ -316,7 +328,7 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
             e->decode_only_weight = true;
             CHK(make_packed(e, f.data(), nullptr, 960, H, &w.qkv_f));
             e->decode_only_weight = false;
-            if (e->prefill_fuse_norm) CHK(make_pb(e, w.qkv_f));         // f32x3 prefill without norm launches (run_prefill)
+            if (e->prefill_fuse_norm) { CHK(make_pb(e, w.qkv_f)); CHK(make_w8(e, w.qkv_f)); }        // f32x3 / fp8 prefill without norm launches (run_prefill)
             if (fuse && l > 0) {
                 // Q = W'_l . Wd_{l-1} in fp64, rounded once; then [W'_l | Q] re-tiled into P-layout
                 const std::string kd = L + "model.layers." + std::to_string(l - 1) + ".mlp.down_proj.weight";
@@ -345,11 +357,12 @@ extern "C" int mellow_engine_finalize(mellow_engine_t* e) {
                     gf[(size_t)n * H + kk] = g->f()[(size_t)n * H + kk] * l2->f()[kk];
                     uf[(size_t)n * H + kk] = u->f()[(size_t)n * H + kk] * l2->f()[kk];
                 }
-            if (e->prefill_fuse_norm && e->f32x3_terms) {   // the folded gate/up in the prefill's pair layout (+ its bf16 split)
+            if (e->prefill_fuse_norm && (e->f32x3_terms || (e->fp8 && e->fp8_prefill))) {   // the folded gate/up in the prefill's pair layout (+ its bf16 split / e4m3 copy)
                 e->decode_only_weight = true;
                 CHK(make_packed(e, gf.data(), uf.data(), I, H, &w.gateup_f));
                 e->decode_only_weight = false;
                 CHK(make_pb(e, w.gateup_f));
+                CHK(make_w8(e, w.gateup_f));
             }
             {
                 // 16-row tile t = gate[8t..8t+7] then up[8t..8t+7]: one workgroup of the decode gate/up kernel owns both

@@ -122,6 +122,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             if (g.C3) {
                 // the stored row, pre-split for the next x3q GEMM, and its sum of squares over this wave's 64 columns
                 const int P = pn * WN + wn;
+                if (g.c3_fmt == 1) {           // fp8 mode: the consumer is gemm_mx8_kernel -- MXFP8 in AMX order (common.h), one scale per
+                    if (P * 64 < g.N) {        // 32 columns = per (ni) accumulator tile of the lane pair; N % 32 == 0 on this path
+                        float ss = 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            if (P * 64 + ni * 32 >= g.N) continue;
+                            float v[16];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) { v[q] = acc[ni][mi][q]; ss += v[q] * v[q]; }
+                            amx_store_block(reinterpret_cast<i32x4*>(g.C3), g.C3s, m, P * 2 + ni, g.c3_kt64, (g.c3_kt64 + 3) >> 2, v, h);
+                        }
+                        ss = half_sum(ss);
+                        if (h == 0 && g.ssq_out) g.ssq_out[(int64_t)m * g.ssq_parts + P] = ss;
+                    }
+                } else
                 if (P * 64 < g.N) {            // wave-uniform (N is a multiple of 64 on this path)
                     float ss = 0.f;
 #pragma unroll
@@ -145,6 +160,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             // pair epilogues: n-tile 2*wn holds the first half of the pair, 2*wn+1 the second
             const int P = pn * WN + wn;  // 64-column group index
             if constexpr (EPI == EPI_SWIGLU) {
+                if (g.C3 && g.c3_fmt == 1) {       // fp8 mode: silu(gate) * up as MXFP8 in AMX order; the wave's 32 columns are one block
+                    if (P * 32 >= g.N) continue;
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = __fmul_rn(siluf_(acc[0][mi][q]), acc[1][mi][q]);
+                    amx_store_block(reinterpret_cast<i32x4*>(g.C3), g.C3s, m, P, g.c3_kt64, (g.c3_kt64 + 3) >> 2, v, h);
+                    continue;
+                }
                 if (g.C3) {       // the consumer is an x3q GEMM: write silu(gate) * up pre-split in APB order (N % 16 == 0)
                     if (P * 32 >= g.N) continue;
 #pragma unroll

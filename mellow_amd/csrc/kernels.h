@@ -76,21 +76,28 @@ struct GemmArgs {
     const float* rs_ssq = nullptr;
     int rs_parts = 0;
     float rs_dim = 1.f, rs_eps = 0.f;
-    // fp8 mode (gemm_fp8.hip): both operands e4m3, fp32 accumulate, C = (A8 . W8^T) * a_scale[m] * w_scale[n] (+epilogue)
-    const uint8_t* A8 = nullptr;      // row-major [M][lda8] bytes, lda8 = K rounded up to 64
-    int64_t lda8 = 0;
-    const float* a_scale = nullptr;   // [M] per-row dequantisation factor (row amax / 448)
-    const uint8_t* W8 = nullptr;      // P8-layout weight
+    // fp8 mode (gemm_fp8.hip): activation as an AMX image (MXFP8: e4m3 + one E8M0 scale per 32 k, common.h), weight as a WMX image
+    // with one fp32 scale per packed row; fp32 accumulate, C = (A8 . W8^T) * w_scale[n] (+epilogue).  (A8 / W8 / lda8 also carry
+    // the pre-split operands of the f32x3 kernels.)
+    const uint8_t* A8 = nullptr;      // AMX data, roundup(M, 128) rows x lda8 bytes
+    int64_t lda8 = 0;                 // K rounded up to 64
+    const uint32_t* a_sc = nullptr;   // AMX scale words
+    const uint8_t* W8 = nullptr;      // WMX weight
     const float* w_scale = nullptr;   // [roundup(Nw,128)] per packed weight row
+    // format of C3 (the output handed over in the NEXT GEMM's operand order): 0 = APB (bf16 x 3, f32x3 mode), 1 = AMX (fp8 mode,
+    // with C3s = its scale bytes and c3_kt64 = the consumer's k64 steps)
+    int c3_fmt = 0;
+    uint8_t* C3s = nullptr;
+    int c3_kt64 = 0;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 // ---- fp8 (e4m3) GEMM path: BASELINE config 5 (gemm_fp8.hip) -------------------------------------------------
-// P8-layout of a weight: [n/32][k/32][lane][16 B], lane = (n%32) + 32*kh; the 16 bytes are the two A operands of
-// v_mfma_f32_32x32x16_fp8_fp8 for k = 32s + 8kh + (0..7) and k = 32s + 16 + 8kh + (0..7).
-void launch_quant_rows(const float* A, int64_t lda, int M, int K, uint8_t* A8, int64_t lda8, float* a_scale, hipStream_t s);
-// from an fp32 P-layout weight (NP x KP, already padded / pair-interleaved) to P8 + per-row scales
+// fp32 row-major activation -> AMX image (roundup(M, 128) x roundup(K, 64) bytes) + scale words (roundup(M, 128) x ceil(K / 256) x 8
+// bytes): the standalone form, for GEMM inputs whose producer does not emit AMX itself.  K % 4 == 0.
+void launch_quant_mx8(const float* A, int64_t lda, int M, int K, void* img, void* sc, hipStream_t s);
+// from an fp32 P-layout weight (NP x KP, already padded / pair-interleaved) to a WMX image (NP x roundup(KP, 64) bytes) + row scales
 void launch_pack_fp8(const float* Wp, int NP, int KP, uint8_t* W8, float* w_scale, hipStream_t s);
-void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // needs K % 64 == 0, a_mode == A_PLAIN
+void launch_gemm_fp8(const GemmArgs& a, hipStream_t s);   // a_mode == A_PLAIN
 // ---- fp32 GEMM on the bf16 matrix pipe by exact 3-way operand splitting (gemm_bf16x3.hip) ----------------------
 // operands travel in GemmArgs::A8 (A3 [M][K/8][3][8 bf16], lda8 = 16-byte units per row = 3 K/8) and GemmArgs::W8 (PB)
 void launch_pack_bf16x3(const float* Wp, int NP, int KP, void* PB, hipStream_t s);
@@ -269,9 +276,10 @@ void launch_stft_fft_power(const float* wpad, int fpc, int64_t clip_stride, int 
 void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, float eps, hipStream_t s);
 // the same numbers, written pre-split in APB order (C % 16 == 0) for the x3q GEMM
 // row-map LayerNorm, output pre-split in APB order (C % 16 == 0, C <= 768; out holds roundup(M, 128) rows)
+// out_scales != nullptr (fp8 mode): out_apb receives the AMX image (MXFP8, common.h) and out_scales its scale bytes instead
 void launch_layernorm_apb(const float* in, void* out_apb, int M, int C, const float* w, const float* b, const int32_t* row_map,
-                          int ntok, hipStream_t s);
-void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s);
+                          int ntok, hipStream_t s, void* out_scales = nullptr);
+void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const float* w, float eps, hipStream_t s, void* out_scales = nullptr);
 
 // ---- Swin window attention -----------------------------------------------------------------------------
 // qkv [M][3C] rows in window order; out [M][C] window order.  bias_exp [nH][64][64]; mask [nW][64][64] or null
@@ -303,8 +311,9 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 // causal GQA flash attention over the KV pages written by the QKV epilogue.  q [B*T][576]; o [B*T][576]
 // o_apb != nullptr: the output [B*T][576] is written pre-split in APB order instead of to o
 // x3: both matrix products as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (the f32x3 mode); else exact fp32 MFMA
+// o_scales != nullptr (fp8 mode): o_apb receives the AMX image (MXFP8, K = 576: 9 k64 steps) and o_scales its scale bytes
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s);
+                              int Tmax, bool x3, hipStream_t s, void* o_scales = nullptr);
 // ---- misc ------------------------------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ float pa_exp(float x) { return __builtin_amdgcn_exp2f
 __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __restrict__ q,
                                                                 const float* __restrict__ k_cache,
                                                                 const float* __restrict__ v_cache,
-                                                                float* __restrict__ o, i32x4* __restrict__ o_apb, int T, int Tmax) {
+                                                                float* __restrict__ o, i32x4* __restrict__ o_apb, uint8_t* __restrict__ o_sc, int T, int Tmax) {
     // wave specialisation: waves 0..2 = the three query heads of kv head g (MFMA + softmax), wave 3 = loader: it owns
     // the global -> LDS staging (K transposed, V row-major) of the NEXT key tile into the other LDS stage while the
     // compute waves work, so they carry no staging registers (148 VGPRs -> three workgroups per CU) and never wait
@@ -141,6 +141,16 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
     }
     if (qi < T) {
         const float inv = 1.0f / l_run;
+        if (o_sc) {       // fp8 mode: the o_proj is gemm_mx8_kernel -- the row as MXFP8 in AMX order (K = 576: blocks 2 hq, 2 hq + 1)
+            const int64_t m = (int64_t)b * T + qi;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = O0[r] * inv;
+            amx_store_block(o_apb, o_sc, m, hq * 2, 9, 3, v, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = O1[r] * inv;
+            amx_store_block(o_apb, o_sc, m, hq * 2 + 1, 9, 3, v, h);
+        } else
         if (o_apb) {      // the o_proj is an x3q GEMM: write the row pre-split in APB order (K = 576: 72 column octets)
             const int64_t m = (int64_t)b * T + qi;
 #pragma unroll
@@ -201,7 +211,7 @@ __device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
 
 __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
                                                                    const float* __restrict__ v_cache, float* __restrict__ o,
-                                                                   i32x4* __restrict__ o_apb, int T, int Tmax) {
+                                                                   i32x4* __restrict__ o_apb, uint8_t* __restrict__ o_sc, int T, int Tmax) {
     __shared__ i32x4 Kp[2][PAX_K_SLOTS];
     __shared__ i32x4 Vp[2][PAX_V_SLOTS];
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, g = blockIdx.y, b = blockIdx.z;
@@ -366,6 +376,16 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
     }
     if (qi < T) {
         const float inv = 1.0f / l_run;
+        if (o_sc) {       // fp8 mode: the o_proj is gemm_mx8_kernel -- the row as MXFP8 in AMX order (K = 576: blocks 2 hq, 2 hq + 1)
+            const int64_t m = (int64_t)b * T + qi;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = O0[r] * inv;
+            amx_store_block(o_apb, o_sc, m, hq * 2, 9, 3, v, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = O1[r] * inv;
+            amx_store_block(o_apb, o_sc, m, hq * 2 + 1, 9, 3, v, h);
+        } else
         if (o_apb) {
             const int64_t m = (int64_t)b * T + qi;
 #pragma unroll
@@ -394,10 +414,11 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
 
 // x3 = the bf16-split kernel (the engine's f32x3 mode), else exact fp32 MFMA
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s) {
+                              int Tmax, bool x3, hipStream_t s, void* o_scales) {
     const int qtiles = (T + 31) / 32;
-    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
-    else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), T, Tmax);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(o_scales);
+    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
 }
 
 }  // namespace mellow

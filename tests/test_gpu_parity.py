@@ -1105,27 +1105,50 @@ def _quant_rows_e4m3(x):
     return (x * inv).to(torch.float8_e4m3fn).to(torch.float32), scale
 
 
+def _quant_mx8(x):
+    """MXFP8 as the engine's producers emit it (mellow_amd/csrc/common.h: amx_store_block): e4m3 elements and, per 32 consecutive
+    k of a row, the smallest power-of-two scale with amax / scale <= 448 (no element clips; an all-zero block takes 2^0).
+    Returns the dequantised values (exact in fp32)."""
+    M, K = x.shape
+    Kp = (K + 31) // 32 * 32
+    xb = torch.zeros(M, Kp, dtype=torch.float32)
+    xb[:, :K] = x
+    xb = xb.view(M, Kp // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    mant, ex = torch.frexp(amax / 448.0)                       # amax / 448 = mant * 2^ex, mant in [0.5, 1)
+    e = torch.where(mant > 0.5, ex, ex - 1)                    # ceil(log2(amax / 448))
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), e), torch.ones_like(amax))
+    q = (xb / scale).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).view(M, Kp)[:, :K]
+
+
 def test_fp8_gemm_matches_quantised_emulation(engine_f32):
-    """The fp8 GEMM == exact products of the SAME e4m3 operands (per-row scales, RNE) accumulated in fp32.
-    Tolerance: fp32 accumulation-order noise (1e-4 of max) plus the rare element whose scaled value sits on a rounding
-    tie and lands one e4m3 step apart (bounded by 2e-3 of max); the quantisation itself costs ~4e-2 vs the exact product."""
+    """The fp8 GEMM (round 6: v_mfma_scale_f32_32x32x64_f8f6f4, activations MXFP8 with one E8M0 scale per 32 k, weights e4m3 per
+    output channel) == exact products of the SAME quantised operands.  Tolerance: the accumulation of the fp8 matrix pipe (measured
+    with tools/microbench/mx8_semantics.hip: ~4e-5 of the largest element, coarser than an fp32 fmaf chain) -> 1e-4 of max for all
+    but a few elements, plus the rare element whose scaled value sits on a rounding tie and lands one e4m3 step apart (bounded by
+    2e-3 of max); the quantisation itself costs percents vs the exact product.  K = 96 and K = 224 exercise the zero-padded k64
+    tail, M = 70 / 389 the ragged last row panel."""
     torch.manual_seed(1)
-    for M, N, K in ((70, 36, 64), (389, 576, 576), (300, 960, 1536)):
+    for M, N, K in ((70, 36, 64), (389, 576, 576), (300, 960, 1536), (4097, 288, 96), (129, 128, 224)):
         A = torch.randn(M, K) * (0.2 + 3 * torch.rand(M, 1))
+        A[:, : K // 2] *= 30.0                                         # blocks of very different magnitude inside one row
         W = torch.randn(N, K) * 0.05 * (1 + torch.rand(N, 1))
         A[3] = 0.0                                                     # an all-zero row must quantise to zeros
         got, _ = engine_f32.debug_gemm_fp8(A, W)
-        Aq, sa = _quant_rows_e4m3(A)
+        Aq = _quant_mx8(A)
         Wq, sw = _quant_rows_e4m3(W)
-        ref = (Aq.double() @ Wq.double().T) * sa.double() * sw.double().T
+        ref = (Aq.double() @ Wq.double().T) * sw.double().T
         exact = A.double() @ W.double().T
         scale = float(ref.abs().max())
         d = (got.double() - ref).abs()
         assert torch.isfinite(got).all()
         assert float(d.max()) <= 2e-3 * scale, (M, N, K, float(d.max()), scale)
-        assert float((d > 1e-4 * scale).double().mean()) < 1e-3          # almost every element is accumulation noise only
+        assert float((d > 1e-4 * scale).double().mean()) < 1e-3, (M, N, K)          # almost every element is accumulation noise only
         assert float(got[3].abs().max()) == 0.0
-        assert float((ref - exact).abs().max()) > 5e-3 * scale            # sanity: the emulation really is quantised
+        assert float((ref - exact).abs().max()) > 2e-3 * scale            # sanity: the emulation really is quantised
+        # block scaling: a row's small-magnitude half keeps its own precision (a per-row scale would lose it to the 30x larger half)
+        assert float((Aq[:, K // 2:] - A[:, K // 2:]).abs().max()) <= 0.07 * float(A[:, K // 2:].abs().max())
 
 
 def test_fp8_decode_weights_equal_their_dequantised_fp32_form(synth_sd, golden_dir):
@@ -1283,9 +1306,12 @@ def test_fp8_decode_on_the_fp8_pipe_stays_near_the_fp32_activation_form(synth_sd
 def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     """precision="fp8": e4m3 GEMMs in the Swin linears and LM prefill, e4m3 WEIGHTS in the five decode GEMM kernels and the
     lm_head (fp32 activations there); front-end, attentions and norms fp32.  Not bit-exact by design; the test pins (a)
-    determinism, (b) bounded error against the fp32 engine, (c) that the fp32 engine is untouched.  Measured on the synthetic
-    (random-weight, un-trained) checkpoint: prefix rel-rms 5e-2, prefill logits rel-rms 0.17, first-token agreement 0.625 of
-    these 16 rows (0.53 of 32, 0.41 of 64) -- a random network amplifies 3-bit-mantissa noise; see DESIGN.md §6b."""
+    determinism, (b) bounded error against the fp32 engine, (c) that the fp32 engine is untouched, (d) token agreement with the
+    fp32 engine where that number means something.  On the i.i.d.-Gaussian (un-trained) synthetic checkpoint a random network
+    re-amplifies 3-bit-mantissa noise in every layer: first-token agreement there is a coin flip per row (round 5, per-row scales:
+    10 of these 16 rows; round 6, MXFP8 block scales: 7 of 16 -- both inside the binomial noise of p ~ 0.5), so only a loose floor
+    is asserted on it; the meaningful figure is taken on the STRUCTURED checkpoint (decaying singular spectra, synth.py), where
+    round 6 measures first-token 0.84 / position-wise 0.90 over 32 x 64 (round 5: 0.72 / 0.71); see DESIGN.md 6b."""
     from mellow_amd.engine import Engine
     e8 = Engine(device=0, precision="fp8")
     e8.load_state_dict(synth_sd)
@@ -1306,7 +1332,17 @@ def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     assert np.array_equal(t8a, t8b)                                      # deterministic
     t32, *_ = engine_f32.generate(a1, a2, ids, max_len=8, stop_id=0, ignore_stop=True)
     agree = float((t8a[:, 0] == t32[:, 0]).mean())
-    assert agree >= 0.5, agree                                           # measured 0.625 (10 of 16 rows); chance is 1/49152
+    assert agree >= 0.25, agree                                          # i.i.d. checkpoint: noise-dominated (see above); chance is 1/49152
+    # (d) the structured checkpoint: 32 rows x 16 tokens against the fp32-accurate default engine
+    sds = synth.make_state_dict(0, structured=True)
+    es8, es32 = Engine(device=0, precision="fp8"), Engine(device=0, precision="f32x3")
+    es8.load_state_dict(sds); es32.load_state_dict(sds)
+    s1, s2, sid = synth.make_batch(32)
+    ts8, *_ = es8.generate(s1, s2, sid, max_len=16, stop_id=0, ignore_stop=True)
+    ts32, *_ = es32.generate(s1, s2, sid, max_len=16, stop_id=0, ignore_stop=True)
+    first, posw = float((ts8[:, 0] == ts32[:, 0]).mean()), float((ts8 == ts32).mean())
+    assert first >= 0.75 and posw >= 0.70, (first, posw)                 # measured 0.84 / 0.78 over 16 tokens (0.84 / 0.90 over 64: tools/fp8_agreement.py)
+    es8.close(); es32.close()
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     assert np.array_equal(t32[:2], g["tokens"][:, :8])                   # the exact path still matches the reference goldens
     # config 5's batch (128, max_len 64): every quantisation scale belongs to one batch row, so the first 16 rows of the big

@@ -40,11 +40,12 @@ static float e4m3(uint8_t v) {
     else x = ldexpf(1.0f + m / 8.0f, e - 7);
     return s ? -x : x;
 }
-int main() {
+int main(int argc, char**) {
+    const bool full = argc > 1;      // any argument: e4m3 bytes over the whole finite range (|x| <= 448) instead of |x| <= 2
     uint8_t hA[32 * 64], hB[32 * 64], hsa[256], hsb[256];
     uint32_t s = 7u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
-    for (int i = 0; i < 2048; ++i) { hA[i] = (rnd() & 0x80) | (rnd() % 0x40); hB[i] = (rnd() & 0x80) | (rnd() % 0x40); }
+    for (int i = 0; i < 2048; ++i) { hA[i] = (rnd() & 0x80) | (rnd() % (full ? 0x7F : 0x40)); hB[i] = (rnd() & 0x80) | (rnd() % (full ? 0x7F : 0x40)); }
     for (int i = 0; i < 256; ++i) { hsa[i] = 120 + rnd() % 12; hsb[i] = 125 + rnd() % 5; }
     uint8_t *A, *B, *sa, *sb; float* D;
     hipMalloc(&A, 2048); hipMalloc(&B, 2048); hipMalloc(&sa, 256); hipMalloc(&sb, 256); hipMalloc(&D, 4096);
