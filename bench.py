@@ -545,7 +545,7 @@ def main():
             "prefill_parts": eng.prefill_parts(),      # measured by the engine: 2 = two half-batch chains on streams that overlap
             "first_token_ms_p50": round(statistics.median(ftms), 2),
             "phase_ms": {k: round(v, 2) for k, v in phases.items()},
-            "roofline_gemm": {"kernel": ("gemm_fp8_kernel + row quantisation (v_mfma_f32_32x32x16_fp8_fp8) and the fp32 GEMMs left"
+            "roofline_gemm": {"kernel": ("gemm_mx8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4: the block-scaled K = 64 form, the pipe the 5 PF peak refers to; MXFP8 activations emitted by their producers, e4m3 weights per output channel) + the standalone quantiser where no producer emits AMX + the fp32 GEMMs left (front-end mel, lm_forward head)"
                                     if fp8 else "gemm_x3q_kernel (LM prefill, Swin stages 2-3) + gemm_x3w_kernel (stage-0 qkv / fc1) + gemm_x3p_kernel (rest of the encoder): 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
                                     "mel on gemm_x3p_kernel too, the STFT as an FFT (stft_fft_power_kernel, counted in this family); peak = 2.5 PF dense bf16 / 6" if args.precision == "f32x3"
                                     else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32: encoder + LM prefill GEMMs)"),

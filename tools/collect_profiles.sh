@@ -21,6 +21,12 @@ python tools/pmc_traffic.py decode $O/df/f_counter_collection.csv $O/dw/w_counte
 # --- PMC: MFMA utilisation of the GEMM family / attentions ---
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY -d $O/pm -o m --output-format csv -- python tools/pmc_prefill.py --opt prefill_split=1 > $O/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $O/pm/m_counter_collection.csv $O/pmc_gemm_mfma.json || tail -5 $O/pmc_mfma.log
+# the same for the fp8 mode (BASELINE configs[4]; B = 32 here like the f32x3 file: per-launch bytes scale with the rows)
+MELLOW_PRECISION=fp8 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pf8 -o f --output-format csv -- python tools/pmc_prefill.py --opt prefill_split=1 > /dev/null 2>&1
+MELLOW_PRECISION=fp8 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/pw8 -o w --output-format csv -- python tools/pmc_prefill.py --opt prefill_split=1 > /dev/null 2>&1
+MELLOW_PRECISION=fp8 python tools/pmc_traffic.py gemm $O/pf8/f_counter_collection.csv $O/pw8/w_counter_collection.csv $O/pmc_gemm_traffic_fp8.json
+cp $O/pmc_gemm_traffic_fp8.json profiles/${R}_pmc_gemm_traffic_fp8.json
+rm -rf $O/pf8 $O/pw8
 cp $O/pmc_gemm_traffic.json profiles/${R}_pmc_gemm_traffic.json     # bench.py prints `traffic` only from files whose source hash matches
 cp $O/pmc_decode_traffic.json profiles/${R}_pmc_decode_traffic.json
 # --- bench lines ---
@@ -40,6 +46,7 @@ cp $O/stats1/st_kernel_stats.csv $O/bench_onechain_kernel_stats.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace -d $O/trace_dec -o tr --output-format csv -- python tools/decode_probe.py > /dev/null 2>&1
 python tools/trace_summary.py $O/trace_dec/tr_kernel_trace.csv 40 > $O/decode_step_timeline.txt 2>&1
 timeout 400 python tools/fp8_agreement.py structured 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement.txt
+timeout 400 python tools/fp8_agreement.py structured --opt fp8_kv16=0 2>&1 | grep -v amdgpu.ids > $O/fp8_agreement_fp32_pages.txt
 # --- decode phase by batch size: the f32x3 multi-row-block path against the fp32 kernels replicated per row block ---
 { echo "# decode phase of one generate() pass, 63 steps, f32x3 mode (tools/decode_probe.py); x3 = f32x3 forms of the layer GEMM launches from two row blocks on + the streaming lm_head; fp32 = --opt decode_x3=0 (round 4's kernels)";
   for B in 32 64 128 256 512; do echo "B=$B x3  : $(timeout 300 python tools/decode_probe.py $B 64 2>&1 | grep decode_ms)"; echo "B=$B fp32: $(timeout 300 python tools/decode_probe.py $B 64 --opt decode_x3=0 2>&1 | grep decode_ms)"; done; } > $O/decode_batch_table.txt

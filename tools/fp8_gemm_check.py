@@ -21,6 +21,20 @@ def quant_rows(x: torch.Tensor):
     return q, scale
 
 
+def quant_mx8(x: torch.Tensor):
+    """the engine's activation format (mellow_amd/csrc/common.h: amx_store_block), dequantised"""
+    M, K = x.shape
+    Kp = (K + 31) // 32 * 32
+    xb = torch.zeros(M, Kp)
+    xb[:, :K] = x
+    xb = xb.view(M, Kp // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    mant, ex = torch.frexp(amax / 448.0)
+    e = torch.where(mant > 0.5, ex, ex - 1)
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), e), torch.ones_like(amax))
+    return ((xb / scale).to(torch.float8_e4m3fn).to(torch.float32) * scale).view(M, Kp)[:, :K]
+
+
 def main():
     eng = Engine(device=0, max_positions=1024, precision="fp8")
     torch.manual_seed(0)
@@ -28,9 +42,9 @@ def main():
         A = torch.randn(M, K) * torch.rand(M, 1) * 3
         W = torch.randn(N, K) * 0.05 * (1 + torch.rand(N, 1))
         Cc, ms = eng.debug_gemm_fp8(A, W, iters=10)
-        Aq, sa = quant_rows(A)
+        Aq = quant_mx8(A)                       # MXFP8 activations (one power-of-two scale per 32 k), dequantised
         Wq, sw = quant_rows(W)
-        ref = (Aq.double() @ Wq.double().T) * sa.double() * sw.double().T
+        ref = (Aq.double() @ Wq.double().T) * sw.double().T
         exact = A.double() @ W.double().T
         d = (Cc.double() - ref).abs().max().item()
         print(f"M {M} N {N} K {K}: max|gpu - emulation| {d:.3e} (rel {d / ref.abs().max().item():.2e}); "

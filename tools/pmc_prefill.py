@@ -10,7 +10,7 @@ from mellow_amd import synth
 from mellow_amd.engine import Engine
 eng = Engine(device=0, precision=os.environ.get("MELLOW_PRECISION", "f32x3"), options=OPTS)
 eng.load_state_dict(synth.make_state_dict(0))
-B = 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 a1, a2, ids = synth.make_batch(B)
 a1d, a2d, idsd = eng._f32(a1), eng._f32(a2), eng._i32(ids)
 for _ in range(2):

@@ -14,9 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16  # noqa: E402  (bench.py refuses to print a result measured on other kernel sources)
 
 GEMM = ("gemm_f32_kernel", "gemm_x3p_kernel", "gemm_x3q_kernel", "gemm_x3w_kernel", "gemm_bf16x3f_kernel", "stft_fft_power_kernel",
-        "splitk_finish_kernel")          # (the second launch of a split-K GEMM: its bytes count, it is not a launch of its own)
+        "gemm_mx8_kernel", "quant_mx8_kernel", "splitk_finish_kernel")
+HELPERS = ("splitk_finish_kernel", "quant_mx8_kernel")     # the second launch of a split-K GEMM / the standalone quantiser in front of an
+                                                           # fp8 GEMM: their bytes count, they are not launches of their own
 DECODE = ("dec_qkv_kernel", "dec_qkv2_kernel", "dec_attn_kernel", "dec_oproj_kernel", "dec_gateup16_kernel", "dec_down_kernel",
-          "dec_final_norm_kernel", "dec_fullk_kernel", "dec_fullk3_kernel", "dec_head3_kernel", "dec_head3r_kernel", "dec_qkv2x3_kernel",
+          "dec_final_norm_kernel", "dec_fullk_kernel", "dec_head3_kernel", "dec_head3r_kernel", "dec_qkv2x3_kernel",
           "dec_gateup3_kernel", "dec_argmax_kernel", "dec_compact_kernel")
 
 
@@ -37,8 +39,8 @@ def family(path, counter, names):
 mode, fpath, wpath, opath = sys.argv[1:5]
 names = GEMM if mode == "gemm" else DECODE
 pf, pw = family(fpath, "FETCH_SIZE", names), family(wpath, "WRITE_SIZE", names)
-nf, fetch = sum(v[0] for k, v in pf.items() if k != "splitk_finish_kernel"), sum(v[1] for v in pf.values())
-nw, write = sum(v[0] for k, v in pw.items() if k != "splitk_finish_kernel"), sum(v[1] for v in pw.values())
+nf, fetch = sum(v[0] for k, v in pf.items() if k not in HELPERS), sum(v[1] for v in pf.values())
+nw, write = sum(v[0] for k, v in pw.items() if k not in HELPERS), sum(v[1] for v in pw.values())
 assert nf == nw and nf > 0, (nf, nw)
 out = {
     "source_sha16": kernel_source_sha16(),
@@ -52,7 +54,8 @@ if mode == "gemm":
     out.update({
         "kernel": "dense GEMM family of encoder + LM prefill: gemm_x3q_kernel (LM prefill, Swin stages 2-3) / gemm_x3w_kernel (stage 0 qkv, fc1) / "
                   "gemm_x3p_kernel / gemm_bf16x3f_kernel (f32x3 mode) + gemm_f32_kernel (all instances) + stft_fft_power_kernel (the STFT of "
-                  "the f32x3 mode); splitk_finish_kernel's bytes are counted with the launch they complete",
+                  "the f32x3 mode); fp8 mode: gemm_mx8_kernel (+ quant_mx8_kernel where no producer emits the AMX image); "
+                  "splitk_finish_kernel's / quant_mx8_kernel's bytes are counted with the launch they serve",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_prefill.py (2 encoder+prefill passes at "
                   "B=32, in the `precision` mode); reduced with tools/pmc_traffic.py gemm",
         "fetch_bytes_per_launch_x2_corrected": 2.0 * fetch * 1024.0 / nf,
