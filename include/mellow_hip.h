@@ -258,7 +258,7 @@ int         mellow_engine_set_precision(mellow_engine_t* e, int mode);
  *      ("arena_mb": before the first mellow_engine_load_tensor); an unknown key or a malformed value is an error.  The defaults
  *      are the configuration bench.py measures and the parity suite runs; the reference has no counterpart (wrapper.py:35-49 has
  *      no hidden modes, and neither has a default engine).  Keys: prefill_split, prefill_fuse_norm, decode_fuse,
- *      decode_fuse_max_rb, splitk, enc_apb, graph, fp8_decode, fp8_prefill, fp8_decode_act, fp8_kv16, decode_x3, decode_x3_min_rb,
+ *      decode_fuse_max_rb, splitk, enc_apb, graph, fp8_decode, fp8_prefill, fp8_decode_act, fp8_kv16, fp8_attn_bf16, decode_x3, decode_x3_min_rb,
  *      x3_stft, stft_fft, x3_apb, x3_attn, x3w, row_migration, arena_mb (mellow_amd/csrc/engine.cpp: kOptions says what each does
  *      and whether it can change the answers). */
 int         mellow_engine_set_option(mellow_engine_t* e, const char* key, const char* value);

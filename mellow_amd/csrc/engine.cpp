@@ -397,6 +397,7 @@ static const OptDesc kOptions[] = {
     {"fp8_prefill", "1", true, "fp8 mode: e4m3 GEMMs in encoder + LM prefill"},
     {"fp8_decode_act", "1", true, "fp8 mode: e4m3 activations in the decode GEMM kernels (fp8 matrix pipe)"},
     {"fp8_kv16", "1", true, "fp8 mode: bf16 shadow of the K/V pages for the decode step"},
+    {"fp8_attn_bf16", "1", true, "fp8 mode: prefill attention on operands rounded once to bf16 (0 = the fp32-accurate 3-way split of the f32x3 mode)"},
     {"decode_x3", "7", true, "f32x3: mask of decode GEMM launches on the bf16 pipe (1 lm_head, 2 gate/up, 4 fused down + q/k/v)"},
     {"decode_x3_min_rb", "2", true, "f32x3: fewest 32-row blocks at which the layer launches take their f32x3 forms"},
     {"x3_stft", "1", true, "f32x3: STFT / mel GEMMs on the split kernel (0 = exact fp32 kernel)"},
@@ -437,6 +438,7 @@ int apply_options(mellow_engine* e) {
     e->fp8_decode = e->fp8 && opt_val(e, "fp8_decode") != 0;
     e->fp8_decode_act = e->fp8_decode && opt_val(e, "fp8_decode_act") != 0;
     e->fp8_prefill = opt_val(e, "fp8_prefill") != 0;
+    e->fp8_attn_bf16 = opt_val(e, "fp8_attn_bf16") != 0;
     e->kv16 = e->fp8_decode && opt_val(e, "fp8_kv16") != 0;      // fp8 mode: bf16 shadow pages for the decode step
     // f32x3: six partial products (a2*b3, a3*b2, a3*b3 dropped: < 2^-23 |a*b| in total); measured error against an fp64 product is
     // identical to the nine-term form and slightly below the fp32 MFMA kernel's (tools/f32x3_check.py)
@@ -568,7 +570,7 @@ int mellow_engine_fork(mellow_engine_t* parent, mellow_engine_t** out) {
     c->opts = parent->opts; c->mode = parent->mode; c->x3_stft = parent->x3_stft; c->stft_fft = parent->stft_fft; c->x3_apb = parent->x3_apb; c->x3_attn = parent->x3_attn; c->x3w = parent->x3w;
     c->row_migration = parent->row_migration; c->decode_fuse = parent->decode_fuse; c->arena_mb = parent->arena_mb;
     c->prefill_fuse_norm = parent->prefill_fuse_norm; c->dec_fuse_max_rb = parent->dec_fuse_max_rb; c->enc_apb_stages = parent->enc_apb_stages; c->sk_max = parent->sk_max;
-    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->kv16 = parent->kv16; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3; c->dec_x3_min_rb = parent->dec_x3_min_rb;
+    c->fp8 = parent->fp8; c->fp8_decode = parent->fp8_decode; c->fp8_decode_act = parent->fp8_decode_act; c->fp8_prefill = parent->fp8_prefill; c->fp8_attn_bf16 = parent->fp8_attn_bf16; c->kv16 = parent->kv16; c->f32x3_terms = parent->f32x3_terms; c->dec_x3 = parent->dec_x3; c->dec_x3_min_rb = parent->dec_x3_min_rb;
     // weight pointers (device memory owned by the parent)
     c->dft = parent->dft; c->mel = parent->mel; c->fft_win = parent->fft_win; c->fft_tw1 = parent->fft_tw1; c->fft_tw2 = parent->fft_tw2;
     c->bn_alpha = parent->bn_alpha; c->bn_beta = parent->bn_beta;

@@ -200,6 +200,7 @@ struct mellow_engine {
     bool fp8 = false;
     bool fp8_decode = false;                     // fp8 mode: the decode kernels read e4m3 weights too (option "fp8_decode")
     bool fp8_decode_act = false;                 // ... and quantise their activations: fp8 matrix pipe (option "fp8_decode_act")
+    bool fp8_attn_bf16 = true;                   // fp8 mode: prefill attention on operands rounded once to bf16 (option "fp8_attn_bf16" = 0: the exact 3-way split)
     bool fp8_prefill = true;                     // fp8 mode: e4m3 GEMMs in encoder + prefill (option "fp8_prefill" = 0: a test isolating the decode weights)
     float *head8 = nullptr, *head_sc = nullptr;  // e4m3 lm_head for the decode step
     int dec_x3_min_rb = 2;                       // ... and the fewest 32-row blocks at which the layer GEMM launches take their f32x3 forms (option "decode_x3_min_rb")

@@ -236,7 +236,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
                 // causal QK^T + PV: 4*64 flops per (query,key) pair per head
                 ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)Bh * ((double)T * (T + 1) / 2), 0);
                 const bool attn_f32 = !e->x3_attn;   // option "x3_attn" = 0: f32x3 mode on the fp32 kernel (A/B)
-                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, (e->f32x3_terms != 0 || amx) && !attn_f32, st, o3s);
+                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, (e->f32x3_terms != 0 || amx) && !attn_f32, st, o3s, amx && e->fp8_attn_bf16);
             }
             {
                 GemmArgs g = lin(oh, 576, Mh, w.o, xh, 576, nullptr);

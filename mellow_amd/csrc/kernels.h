@@ -311,9 +311,10 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 // causal GQA flash attention over the KV pages written by the QKV epilogue.  q [B*T][576]; o [B*T][576]
 // o_apb != nullptr: the output [B*T][576] is written pre-split in APB order instead of to o
 // x3: both matrix products as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (the f32x3 mode); else exact fp32 MFMA
+// bf16_once (fp8 mode): operands rounded once to bf16 instead of split exactly in three (plain bf16 flash attention)
 // o_scales != nullptr (fp8 mode): o_apb receives the AMX image (MXFP8, K = 576: 9 k64 steps) and o_scales its scale bytes
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s, void* o_scales = nullptr);
+                              int Tmax, bool x3, hipStream_t s, void* o_scales = nullptr, bool bf16_once = false);
 // ---- misc ------------------------------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);
 

@@ -199,7 +199,7 @@ constexpr int PAX_LOADERS = MELLOW_PAX_LOADERS, PAX_THREADS = (3 + PAX_LOADERS) 
 #ifndef MELLOW_PAX_MINW
 #define MELLOW_PAX_MINW 2      // waves per SIMD the register allocation must allow (2 workgroups of 4 waves per CU)
 #endif
-constexpr int PAX_K_SLOTS = 4 * 3 * 64, PAX_V_SLOTS = 2 * 2 * 3 * 64;
+constexpr int PAX_K_SLOTS = 4 * 3 * 64, PAX_V_SLOTS = 2 * 2 * 3 * 64;          // per stage at NP = 3 pieces (NP = 1: a third)
 #ifndef MELLOW_PAX_ABL
 #define MELLOW_PAX_ABL 0      // developer ablations (wrong results, timing only; tools/microbench/prefill_attn_bench.hip): 1 loader stores
 #endif                        // unsplit bits, 2 no softmax arithmetic, 4 no split of P, 8 no score MFMAs, 16 no PV MFMAs, 32 loader fetches tile 0 only
@@ -209,11 +209,26 @@ __device__ __forceinline__ int pax_sw(int l) { return l ^ ((l >> 3) & 3); }
 #define PAX_6(A0, A1, A2, B0, B1, B2, ACC) \
     do { PAX_MFMA(A2, B0, ACC); PAX_MFMA(A1, B1, ACC); PAX_MFMA(A0, B2, ACC); PAX_MFMA(A1, B0, ACC); PAX_MFMA(A0, B1, ACC); PAX_MFMA(A0, B0, ACC); } while (0)
 
+// NP = 3: the exact 3-way split (f32x3 mode, fp32-accurate).  NP = 1 (fp8 mode, round 6): K, Q, P and V rounded once to bf16 -- the
+// plain bf16 flash attention on the same plumbing (8 MFMAs per 32 x 32 tile instead of 48, no split arithmetic): BASELINE config 5
+// quantises every GEMM operand to e4m3 (3 mantissa bits) around it, so an 8-bit-mantissa attention is not what bounds its accuracy
+// (agreement figures: DESIGN.md 6b); softmax statistics, accumulation and the K/V pages stay fp32.
+template <int NP>
+__device__ __forceinline__ void pax_split(const float (&v)[8], i32x4 (&p)[NP]) {
+    if constexpr (NP == 3) split8(v, p[0], p[1], p[2]);
+    else {
+        bf16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = static_cast<__bf16>(v[j]);
+        p[0] = __builtin_bit_cast(i32x4, h);
+    }
+}
+template <int NP>
 __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
                                                                    const float* __restrict__ v_cache, float* __restrict__ o,
                                                                    i32x4* __restrict__ o_apb, uint8_t* __restrict__ o_sc, int T, int Tmax) {
-    __shared__ i32x4 Kp[2][PAX_K_SLOTS];
-    __shared__ i32x4 Vp[2][PAX_V_SLOTS];
+    __shared__ i32x4 Kp[2][4 * NP * 64];
+    __shared__ i32x4 Vp[2][2 * 2 * NP * 64];
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* kpage = k_cache + ((int64_t)b * 3 + g) * Tmax * 64;
@@ -249,20 +264,22 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
             for (int i = 0; i < 4; ++i) {
                 const float v[8] = {pk[2 * i][0], pk[2 * i][1], pk[2 * i][2], pk[2 * i][3],
                                     pk[2 * i + 1][0], pk[2 * i + 1][1], pk[2 * i + 1][2], pk[2 * i + 1][3]};
-                i32x4 p0, p1, p2;
-                if (MELLOW_PAX_ABL & 1) { p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; p2 = p0; } else split8(v, p0, p1, p2);
-                i32x4* dst = &Kp[st][((oct >> 1) * 3) * 64 + klo + 8 * i + 32 * (oct & 1)];
-                dst[0] = p0; dst[64] = p1; dst[128] = p2;
+                i32x4 pc[NP];
+                if (MELLOW_PAX_ABL & 1) { for (int z = 0; z < NP; ++z) pc[z] = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; } else pax_split<NP>(v, pc);
+                i32x4* dst = &Kp[st][((oct >> 1) * NP) * 64 + klo + 8 * i + 32 * (oct & 1)];
+#pragma unroll
+                for (int z = 0; z < NP; ++z) dst[z * 64] = pc[z];
             }
             if (doV)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v[8] = {pv[0][e], pv[1][e], pv[2][e], pv[3][e], pv[4][e], pv[5][e], pv[6][e], pv[7][e]};
-                i32x4 p0, p1, p2;
-                if (MELLOW_PAX_ABL & 1) { p0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; p1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; p2 = p0; } else split8(v, p0, p1, p2);
+                i32x4 pc[NP];
+                if (MELLOW_PAX_ABL & 1) { for (int z = 0; z < NP; ++z) pc[z] = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; } else pax_split<NP>(v, pc);
                 const int d = 4 * q4 + e;
-                i32x4* dst = &Vp[st][((t2 * 2 + (d >> 5)) * 3) * 64 + pax_sw((d & 31) + 32 * hv)];
-                dst[0] = p0; dst[64] = p1; dst[128] = p2;
+                i32x4* dst = &Vp[st][((t2 * 2 + (d >> 5)) * NP) * 64 + pax_sw((d & 31) + 32 * hv)];
+#pragma unroll
+                for (int z = 0; z < NP; ++z) dst[z * 64] = pc[z];
             }
         };
         fetch(0);
@@ -284,14 +301,14 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
     const int qi = q0 + ql;
     const int qc = qi < T ? qi : T - 1;
     // Q as B operand of the bf16 MFMA: step s, lane (query ql, half h) holds d = 16 s + 8 h + (0..7), pre-scaled by 1/8 (exact)
-    i32x4 qp[4][3];
+    i32x4 qp[4][NP];
     {
         const float* qrow = q + ((int64_t)b * T + qc) * 576 + hq * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const float4 a = *reinterpret_cast<const float4*>(qrow + 16 * s), c = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
             const float v[8] = {a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f, c.x * 0.125f, c.y * 0.125f, c.z * 0.125f, c.w * 0.125f};
-            split8(v, qp[s][0], qp[s][1], qp[s][2]);
+            pax_split<NP>(v, qp[s]);
         }
     }
     f32x16 O0, O1;
@@ -312,6 +329,11 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         for (int r = 0; r < 16; ++r) { S[r] = 0.f; S2[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            if constexpr (NP == 1) {
+                const i32x4 a0 = Kc[s * 64], c0 = Kc[(s + 2) * 64];
+                if (MELLOW_PAX_ABL & 8) { S[0] += __int_as_float(a0[0] ^ c0[0]); continue; }
+                PAX_MFMA(a0, qp[s][0], S);      PAX_MFMA(c0, qp[s + 2][0], S2);
+            } else {
             const i32x4 a0 = Kc[(s * 3 + 0) * 64], a1 = Kc[(s * 3 + 1) * 64], a2 = Kc[(s * 3 + 2) * 64];
             const i32x4 c0 = Kc[((s + 2) * 3 + 0) * 64], c1 = Kc[((s + 2) * 3 + 1) * 64], c2 = Kc[((s + 2) * 3 + 2) * 64];
             if (MELLOW_PAX_ABL & 8) { S[0] += __int_as_float(a0[0] ^ a1[1] ^ a2[2] ^ c0[0] ^ c1[1] ^ c2[2]); continue; }
@@ -321,6 +343,7 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
             PAX_MFMA(a1, qp[s][0], S);      PAX_MFMA(c1, qp[s + 2][0], S2);
             PAX_MFMA(a0, qp[s][1], S);      PAX_MFMA(c0, qp[s + 2][1], S2);
             PAX_MFMA(a0, qp[s][0], S);      PAX_MFMA(c0, qp[s + 2][0], S2);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] += S2[r];
@@ -357,10 +380,15 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float v[8] = {p[8 * t], p[8 * t + 1], p[8 * t + 2], p[8 * t + 3], p[8 * t + 4], p[8 * t + 5], p[8 * t + 6], p[8 * t + 7]};
-            i32x4 b0, b1, b2;
-            if (MELLOW_PAX_ABL & 4) { b0 = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; b1 = i32x4{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])}; b2 = b0; }
-            else split8(v, b0, b1, b2);
-            {       // the two d-halves are independent chains: interleave them
+            i32x4 bq[NP];
+            if (MELLOW_PAX_ABL & 4) { for (int z = 0; z < NP; ++z) bq[z] = i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])}; }
+            else pax_split<NP>(v, bq);
+            if constexpr (NP == 1) {
+                const i32x4 a0 = Vc[(t * 2 + 0) * 64], c0 = Vc[(t * 2 + 1) * 64];
+                if (MELLOW_PAX_ABL & 16) { O0[0] += __int_as_float(a0[0] ^ bq[0][0]); O1[0] += __int_as_float(c0[0]); continue; }
+                PAX_MFMA(a0, bq[0], O0);      PAX_MFMA(c0, bq[0], O1);
+            } else {       // the two d-halves are independent chains: interleave them
+                const i32x4 b0 = bq[0], b1 = bq[1], b2 = bq[2];
                 const i32x4 a0 = Vc[((t * 2 + 0) * 3 + 0) * 64], a1 = Vc[((t * 2 + 0) * 3 + 1) * 64], a2 = Vc[((t * 2 + 0) * 3 + 2) * 64];
                 const i32x4 c0 = Vc[((t * 2 + 1) * 3 + 0) * 64], c1 = Vc[((t * 2 + 1) * 3 + 1) * 64], c2 = Vc[((t * 2 + 1) * 3 + 2) * 64];
                 if (MELLOW_PAX_ABL & 16) { O0[0] += __int_as_float(a0[0] ^ a1[1] ^ a2[2] ^ b0[0] ^ b1[1] ^ b2[2]); O1[0] += __int_as_float(c0[0] ^ c1[1] ^ c2[2]); continue; }
@@ -414,10 +442,11 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
 
 // x3 = the bf16-split kernel (the engine's f32x3 mode), else exact fp32 MFMA
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s, void* o_scales) {
+                              int Tmax, bool x3, hipStream_t s, void* o_scales, bool bf16_once) {
     const int qtiles = (T + 31) / 32;
     uint8_t* sc = reinterpret_cast<uint8_t*>(o_scales);
-    if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    if (x3 && bf16_once) hipLaunchKernelGGL(prefill_attention_x3_kernel<1>, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    else if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel<3>, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
     else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
 }
 

@@ -24,14 +24,14 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(q, hq.data(), nq * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(k, hk.data(), nkv * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(v, hv.data(), nkv * 4, hipMemcpyHostToDevice));
         hipStream_t st; CK(hipStreamCreate(&st));
         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-        for (int x3 = 1; x3 >= (argc > 1 ? 0 : 1); --x3) {
-            for (int i = 0; i < 5; ++i) mellow::launch_prefill_attention(q, k, v, o, nullptr, B, T, Tmax, x3, st);
+        for (int x3 = 2; x3 >= (argc > 1 ? 0 : 1); --x3) {      // 2 = operands rounded once to bf16 (fp8 mode), 1 = exact 3-way split, 0 = fp32 MFMA
+            for (int i = 0; i < 5; ++i) mellow::launch_prefill_attention(q, k, v, o, nullptr, B, T, Tmax, x3 != 0, st, nullptr, x3 == 2);
             CK(hipStreamSynchronize(st));
             float best = 1e9f, sum = 0.f;
             const int R = 40;
             for (int i = 0; i < R; ++i) {
                 CK(hipEventRecord(a, st));
-                mellow::launch_prefill_attention(q, k, v, o, nullptr, B, T, Tmax, x3, st);
+                mellow::launch_prefill_attention(q, k, v, o, nullptr, B, T, Tmax, x3 != 0, st, nullptr, x3 == 2);
                 CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
                 float ms; CK(hipEventElapsedTime(&ms, a, b)); sum += ms; best = ms < best ? ms : best;
             }
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(ho.data(), o, nq * 4, hipMemcpyDeviceToHost));
             uint64_t cs = 0; double l1 = 0;
             for (size_t i = 0; i < nq; ++i) { uint32_t u; memcpy(&u, &ho[i], 4); cs = cs * 1099511628211ull + u; l1 += fabs(ho[i]); }
-            printf("B=%d %s abl=%d: avg %.1f us, min %.1f us, checksum %016llx, mean|o| %.6f\n", B, x3 ? "x3" : "f32", MELLOW_PAX_ABL, sum / R * 1e3, best * 1e3,
+            printf("B=%d %s abl=%d: avg %.1f us, min %.1f us, checksum %016llx, mean|o| %.6f\n", B, x3 == 2 ? "bf16" : x3 ? "x3" : "f32", MELLOW_PAX_ABL, sum / R * 1e3, best * 1e3,
                    (unsigned long long)cs, l1 / nq);
         }
         hipFree(q); hipFree(k); hipFree(v); hipFree(o); hipFree(o3);
