@@ -1357,6 +1357,27 @@ def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     e8.close()
 
 
+def test_fp8_mode_bf16_prefill_attention_stays_near_the_exact_one(synth_sd):
+    """fp8 mode, round 6: the LM prefill attention runs on operands rounded ONCE to bf16 (8 MFMAs per 32 x 32 tile instead of the 48
+    of the exact 3-way split; engine option fp8_attn_bf16 = 0 keeps the split).  On the SAME prefix the prefill logits of the two
+    forms differ by what bf16 rounding of q / k / p / v costs after 29 layers of e4m3 GEMMs -- well inside the mode's own distance
+    from the fp32 engine (0.17-0.23 relative rms); a wrong key / lane assignment in the NP = 1 plumbing would be O(1).  Determinism
+    and the two row-count regimes (one chain, two parts) included."""
+    from mellow_amd.engine import Engine
+    eb, ex = Engine(device=0, precision="fp8"), Engine(device=0, precision="fp8", options={"fp8_attn_bf16": 0})
+    eb.load_state_dict(synth_sd); ex.load_state_dict(synth_sd)
+    assert eb.describe()["non_default"] == [] and ex.describe()["non_default"] == ["fp8_attn_bf16"]
+    for B in (1, 2, 33):
+        a1, a2, ids = synth.make_batch(B)
+        pre = ex.prefix(a1, a2, ids)
+        assert torch.equal(pre, eb.prefix(a1, a2, ids))                     # the encoder does not depend on the option
+        lb, lx = eb.lm_prefill(pre, reserve=2), ex.lm_prefill(pre, reserve=2)
+        rel_l = float((lb - lx).pow(2).mean().sqrt() / lx.pow(2).mean().sqrt())
+        assert torch.isfinite(lb).all() and 1e-5 < rel_l < 0.15, (B, rel_l)
+        assert torch.equal(lb, eb.lm_prefill(pre, reserve=2))
+    eb.close(); ex.close()
+
+
 def test_f32x3_mode_is_fp32_accurate(engine_f32, synth_sd, golden_dir):
     """Experimental precision="f32x3": fp32 GEMMs run as exact 3-way bf16 operand splits on the bf16 MFMA pipe.
     (a) one GEMM against an fp64 product: no less accurate than the exact fp32 MFMA kernel (x1.25 slack on max / rms);
