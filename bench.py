@@ -36,11 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
-PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 matrix peak (same guide); the 32x32x16 fp8 form used here sustains 2460
+PEAK_FP8_MFMA_TFLOPS = 5000.0     # dense fp8 matrix peak (same guide): the block-scaled K = 64 form gemm_mx8_kernel issues (4.6 PF measured there)
 PEAK_HBM_GBS = 8000.0
 PEAK_F32X3_TFLOPS = 2500.0 / 6.0   # f32x3 mode: six bf16 MFMA products per fp32 product on the 2.5 PF dense bf16 pipe
-PMC_TRAFFIC_FILE = "r05_pmc_gemm_traffic.json"          # dense GEMM family (tools/pmc_traffic.py gemm)
-PMC_DECODE_FILE = "r05_pmc_decode_traffic.json"         # decode step (tools/pmc_traffic.py decode)
+PMC_TRAFFIC_FILE = "r06_pmc_gemm_traffic.json"          # dense GEMM family (tools/pmc_traffic.py gemm)
+PMC_DECODE_FILE = "r06_pmc_decode_traffic.json"         # decode step (tools/pmc_traffic.py decode)
 FFT_GFLOP_PER_CLIP = 0.051         # algorithmic cost of the STFT; the kernel runs it as a dense DFT GEMM (2.10 GF/clip)
 
 # algorithmic work per response at max_len = 64, prefix 389
@@ -494,7 +494,8 @@ def main():
     eng.prof_enable(False)
 
     if rank == 0:
-        traffic, traffic_note = committed_pmc(PMC_TRAFFIC_FILE, args.precision, "traffic_bytes_per_launch")
+        traffic, traffic_note = committed_pmc(PMC_TRAFFIC_FILE.replace(".json", "_fp8.json") if args.precision == "fp8" else PMC_TRAFFIC_FILE,
+                                              args.precision, "traffic_bytes_per_launch")
         dec_traffic, dec_traffic_note = committed_pmc(PMC_DECODE_FILE, args.precision, "traffic_bytes_per_step")
         total = n_gpus * B * args.steps
         value = total / elapsed
