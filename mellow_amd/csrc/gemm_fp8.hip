@@ -132,6 +132,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(const GemmMxDev p) {
     }
     const int KT = (int)(g.lda8 >> 6);                                     // k64 steps
     const int KQ = (KT + 3) >> 2;
+    // scale words of this panel -> LDS (ordinary loads: they are complete before the first LDS-DMA piece is issued, so the
+    // hand-counted vmcnt of the loop sees LDS-DMA pieces only); row scales of the norm-free chaining likewise
+    {
+        const uint32_t* src = g.a_sc + (int64_t)pm * KQ * 256;
+        for (int i = tid; i < KQ * 256; i += 256) Sc[i] = src[i];
+    }
+    if (g.rs_ssq && tid < BM) {
+        int64_t m = (int64_t)pm * BM + tid;
+        m = m < g.M ? m : g.M - 1;
+        const float* sp = g.rs_ssq + m * g.rs_parts;
+        float ss = 0.f;
+        for (int q = 0; q < g.rs_parts; ++q) ss += sp[q];                  // fixed order
+        rs_rows[tid] = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const bool isA = wave < 2;
     const int c0 = (wave & 1) * 4;                                         // pieces c0 .. c0 + 3 of the 8 of a stage
     const char* base = isA ? reinterpret_cast<const char*>(g.A8) + ((int64_t)pm * KT * 8 + c0) * 1024
@@ -161,23 +176,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(const GemmMxDev p) {
     const bool idle = pn * BN + wn * 64 >= g.Nw;            // wave-uniform: its 64 columns lie beyond the weight's rows
     MX_ISSUE(0, 0)
     MX_ISSUE(1, 1)
-    // scale words of this panel -> LDS, row scales of the norm-free chaining likewise: ordinary loads, issued BEHIND the first two
-    // LDS-DMA stages so that their latency and the ring's fill overlap (loads complete in order: whatever the compiler waits for on
-    // its own loads also covers the older LDS-DMA pieces; the explicit wait below leaves only LDS-DMA pieces for the loop's
-    // hand-counted vmcnt to see)
-    {
-        const uint32_t* src = g.a_sc + (int64_t)pm * KQ * 256;
-        for (int i = tid; i < KQ * 256; i += 256) Sc[i] = src[i];
-    }
-    if (g.rs_ssq && tid < BM) {
-        int64_t m = (int64_t)pm * BM + tid;
-        m = m < g.M ? m : g.M - 1;
-        const float* sp = g.rs_ssq + m * g.rs_parts;
-        float ss = 0.f;
-        for (int q = 0; q < g.rs_parts; ++q) ss += sp[q];                  // fixed order
-        rs_rows[tid] = 1.0f / sqrtf(ss / g.rs_dim + g.rs_eps);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int sa0 = 0, sa1 = 0;
     // step T in stage ST: byte OPS of the scale words; the weight's scale operand is the constant 127 = 2^0
 #define MX_STEP(T, ST, OPS)                                                                      \
