@@ -776,19 +776,21 @@ void launch_gather_span(const float* in, int B, int T, int from_pos, int n, floa
     hipLaunchKernelGGL(gather_span_kernel, dim3(n, B), dim3(192), 0, s, in, T, from_pos, n, out);
 }
 // zero the slots [t0, t1) of every KV page (pages x Tmax x 64 floats): plain coalesced float4 stores
-__global__ __launch_bounds__(256) void clear_page_slots_kernel(float* __restrict__ cache, int64_t pages, int Tmax, int t0, int t1) {
-    const int64_t per = (int64_t)(t1 - t0) * 16;                   // float4 per page
+// (f4 = float4 per slot: 16 for fp32 pages, 8 for the bf16 pages of the fp8 mode)
+__global__ __launch_bounds__(256) void clear_page_slots_kernel(float* __restrict__ cache, int64_t pages, int Tmax, int t0, int t1, int f4) {
+    const int64_t per = (int64_t)(t1 - t0) * f4;                   // float4 per page
     const int64_t total = pages * per;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pg = i / per, r = i % per;
-        reinterpret_cast<float4*>(cache + (pg * Tmax + t0) * 64)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(cache + (pg * Tmax + t0) * (f4 * 4))[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-void launch_clear_page_slots(float* cache, int64_t pages, int Tmax, int t0, int t1, hipStream_t s) {
+void launch_clear_page_slots(float* cache, int64_t pages, int Tmax, int t0, int t1, hipStream_t s, bool pages16) {
     if (t1 <= t0 || pages <= 0) return;
-    const int64_t total = pages * (int64_t)(t1 - t0) * 16;
+    const int f4 = pages16 ? 8 : 16;
+    const int64_t total = pages * (int64_t)(t1 - t0) * f4;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(clear_page_slots_kernel, dim3(blocks), dim3(256), 0, s, cache, pages, Tmax, t0, t1);
+    hipLaunchKernelGGL(clear_page_slots_kernel, dim3(blocks), dim3(256), 0, s, cache, pages, Tmax, t0, t1, f4);
 }
 void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(downsample33_kernel, dim3(129, n), dim3(192), 0, s, proj33, out);

@@ -163,6 +163,7 @@ struct mellow_engine {
     Buf wavcat, wpad, power, logmel, X0, X1, T, QKV, H, ats, fpx, fpxavg, latv, emb33, e1, gbuf, sbuf, proj33;
     Buf lm_x, lm_xn, lm_q, lm_o, lm_h, kcache, vcache;
     Buf kcache16, vcache16;      // fp8 mode: bf16 shadow of the pages for the decode step (half the floats of kcache / vcache)
+    bool kv16_direct = false;    // ... and the prefill writes them itself (q/k/v epilogue) and reads them (bf16-once attention): no fp32 pages, no conversion pass
     bool kv16 = false;           // fp8 mode default; option "fp8_kv16" = 0 keeps the decode step on the fp32 pages
     Buf lm_xn3, lm_o3, lm_h3;                  // f32x3 mode: the GEMM inputs of LM prefill, pre-split by their producers (APB order)
     Buf lm_ssq;                                // ... and the per-row sum-of-squares partials of the residual stream (norm-free chaining)

@@ -20,6 +20,10 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         CHK(ensure(e, e->lm_h3, Mq * 1536 * 6 / 4));
         CHK(ensure(e, e->lm_ssq, Mq * 2 * 16));        // two statistics per row (after o_proj / after down), 9 partial sums each
     }
+    // fp8 mode at its defaults: K and V exist as bf16 pages ONLY -- written by the q/k/v epilogue (rounded once), read by the bf16-once
+    // prefill attention and by the decode attention; the fp32 pages and the conversion pass of round 5 are not touched
+    e->kv16_direct = e->kv16 && e->fp8 && e->fp8_prefill && e->fp8_attn_bf16 && e->x3_apb && e->x3_attn && !e->layers.empty() &&
+                     e->fp8_w.count(e->layers[0].qkv.p) != 0;
     dec_prepare_lds_attributes();            // (remembered per device: a no-op after the first call)
     const int Bp = rb_of(B) * 32;
     if (e->kv_B != Bp || e->kv_Tmax != Tmax) {
@@ -35,6 +39,10 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
         // (weight 0 x value): never-written page slots must hold finite numbers
         HIPCHK(hipMemsetAsync(e->kcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
         HIPCHK(hipMemsetAsync(e->vcache.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float), e->stream));
+        if (e->kv16) {
+            HIPCHK(hipMemsetAsync(e->kcache16.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float) / 2, e->stream));
+            HIPCHK(hipMemsetAsync(e->vcache16.p, 0, kv_layer_floats(e) * e->cfg.num_layers * sizeof(float) / 2, e->stream));
+        }
         if (e->step_exec) { hipGraphExecDestroy(e->step_exec); e->step_exec = nullptr; }
         if (e->step_exec8) { hipGraphExecDestroy(e->step_exec8); e->step_exec8 = nullptr; }
     }
@@ -105,7 +113,8 @@ int clear_page_tails(mellow_engine* e, int T, int t_end) {
     const int Tmax = e->kv_Tmax;
     if (t_end > Tmax) t_end = Tmax;
     if (T >= t_end) return 0;
-    launch_clear_page_slots(e->vcache.p, (int64_t)e->cfg.num_layers * e->kv_B * 3, Tmax, T, t_end, e->stream);
+    if (e->kv16_direct) launch_clear_page_slots(e->vcache16.p, (int64_t)e->cfg.num_layers * e->kv_B * 3, Tmax, T, t_end, e->stream, true);
+    else launch_clear_page_slots(e->vcache.p, (int64_t)e->cfg.num_layers * e->kv_B * 3, Tmax, T, t_end, e->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -194,8 +203,11 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
             float* qh = e->lm_q.p + r0 * 576;
             float* oh = e->lm_o.p + r0 * 576;
             float* hh = e->lm_h.p + r0 * 1536;
-            float* kc = e->kcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
-            float* vc = e->vcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
+            const bool p16 = amx && e->kv16_direct;          // bf16 pages: the same element offsets, two bytes each
+            float* kc = p16 ? e->kcache16.p + (kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64) / 2
+                            : e->kcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
+            float* vc = p16 ? e->vcache16.p + (kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64) / 2
+                            : e->vcache.p + kv_layer_floats(e) * l + (size_t)hb0[h] * 3 * Tmax * 64;
             // pre-split operand regions of this half (6 bytes per element, whole 128-row panels)
             char* xn3 = apb ? reinterpret_cast<char*>(e->lm_xn3.p) + prow[h] * 576 * 6 : nullptr;
             char* o3 = apb ? reinterpret_cast<char*>(e->lm_o3.p) + prow[h] * 576 * 6 : nullptr;
@@ -226,7 +238,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
                 g.A = xnh; g.lda = 576; g.M = Mh; g.K = 576; g.Wp = fz_in ? w.qkv_f.p : w.qkv.p; g.Nw = 960; g.N = 960; g.epi = EPI_QKV_ROPE;
                 if (fz_in) with_rs(g, ssq_in);
                 g.q_out = qh; g.k_cache = kc; g.v_cache = vc; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin;
-                g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3;
+                g.T = T; g.Tmax = Tmax; g.q_heads = 9; g.kv_heads = 3; g.kv16 = p16 ? 1 : 0;
                 if (apb) CHK(run_gemm_apb(e, g, xn3, st, xn3s)); else CHK(run_gemm(e, g));
             }
             // The LAST layer only has to produce the final prefix row (nothing consumes the other rows' attention / MLP
@@ -236,7 +248,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
                 // causal QK^T + PV: 4*64 flops per (query,key) pair per head
                 ProfScope ps(e, PF_PREFILL_ATTN, 4.0 * 64 * 9 * (double)Bh * ((double)T * (T + 1) / 2), 0);
                 const bool attn_f32 = !e->x3_attn;   // option "x3_attn" = 0: f32x3 mode on the fp32 kernel (A/B)
-                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, (e->f32x3_terms != 0 || amx) && !attn_f32, st, o3s, amx && e->fp8_attn_bf16);
+                launch_prefill_attention(qh, kc, vc, oh, apb ? o3 : nullptr, Bh, T, Tmax, (e->f32x3_terms != 0 || amx) && !attn_f32, st, o3s, amx && e->fp8_attn_bf16, p16);
             }
             {
                 GemmArgs g = lin(oh, 576, Mh, w.o, xh, 576, nullptr);
@@ -264,7 +276,7 @@ int run_prefill(mellow_engine* e, int B, int T, const RecordArgs* rec, bool all_
         if (last) break;
     }
     CHK(join.run());
-    if (e->kv16 && !all_positions) {
+    if (e->kv16 && !e->kv16_direct && !all_positions) {
         // fp8 mode: the decode step streams a bf16 shadow of the pages (whole pages: the cleared tails travel with them)
         ProfScope ps(e, PF_MISC, 0, 3.0 * kv_layer_floats(e) * NL * 4);
         launch_kv_to_bf16(e->kcache.p, e->kcache16.p, (int64_t)(kv_layer_floats(e) * NL), s);

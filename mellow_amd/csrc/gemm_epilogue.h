@@ -8,6 +8,14 @@
 
 namespace mellow {
 
+__device__ __forceinline__ void store4_bf16(__bf16* dst, const float (&v)[4]) {
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    bf16x4_ h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = static_cast<__bf16>(v[j]);
+    *reinterpret_cast<bf16x4_*>(dst) = h;
+}
+
 template <int WN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int pm, int pn, int wm, int wn,
                                               int lane, int BM, int BN, const float* rs_rows = nullptr) {
@@ -235,15 +243,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                             o1[j] = __fadd_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(-x2[j], sn[j]));
                             o2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
                         }
+                        if (P >= g.q_heads && g.kv16) {      // fp8 mode: the key goes straight into the bf16 page (rounded once, RNE)
+                            __bf16* d16 = reinterpret_cast<__bf16*>(g.k_cache) + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
+                            store4_bf16(d16 + i0, o1);
+                            store4_bf16(d16 + 32 + i0, o2);
+                        } else {
                         float* dst;
                         if (P < g.q_heads) dst = g.q_out + (int64_t)m * (g.q_heads * 64) + P * 64;
                         else dst = g.k_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
                         *reinterpret_cast<float4*>(dst + i0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
                         *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                        }
                     } else if (P < g.q_heads + 2 * g.kv_heads) {
+                        if (g.kv16) {
+                            __bf16* d16 = reinterpret_cast<__bf16*>(g.v_cache) + (((int64_t)b * g.kv_heads + (P - g.q_heads - g.kv_heads)) * g.Tmax + t) * 64;
+                            store4_bf16(d16 + i0, x1);
+                            store4_bf16(d16 + 32 + i0, x2);
+                        } else {
                         float* dst = g.v_cache + (((int64_t)b * g.kv_heads + (P - g.q_heads - g.kv_heads)) * g.Tmax + t) * 64;
                         *reinterpret_cast<float4*>(dst + i0) = make_float4(x1[0], x1[1], x1[2], x1[3]);
                         *reinterpret_cast<float4*>(dst + 32 + i0) = make_float4(x2[0], x2[1], x2[2], x2[3]);
+                        }
                     }
                 }
             }

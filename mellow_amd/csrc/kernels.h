@@ -58,6 +58,7 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
+    int kv16 = 0;               // fp8 mode: k_cache / v_cache are bf16 pages (same element order, 2-byte elements): keys and values are stored rounded once
     // EPI_SWIGLU: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C.
     // EPI_LINEAR (round 4, norm-free chaining of the f32x3 LM prefill): when set, the stored value (accumulator + bias +
     // residual) is written to C AND pre-split to C3, and ssq_out[m * ssq_parts + P] receives its sum of squares over the
@@ -303,7 +304,7 @@ void launch_gather_rows(const float* table, int width, const int32_t* ids, int n
 // out [B][n][576] = in [B][T][576] rows from_pos .. from_pos + n - 1
 void launch_gather_span(const float* in, int B, int T, int from_pos, int n, float* out, hipStream_t s);
 // zero the token slots [t0, t1) of `pages` KV pages of Tmax x 64 floats each
-void launch_clear_page_slots(float* cache, int64_t pages, int Tmax, int t0, int t1, hipStream_t s);
+void launch_clear_page_slots(float* cache, int64_t pages, int Tmax, int t0, int t1, hipStream_t s, bool pages16 = false);
 // audio129 [n][129][576] from proj33 [n][33][576] (tap / mellow_encode)
 void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 
@@ -314,7 +315,7 @@ void launch_downsample33(const float* proj33, int n, float* out, hipStream_t s);
 // bf16_once (fp8 mode): operands rounded once to bf16 instead of split exactly in three (plain bf16 flash attention)
 // o_scales != nullptr (fp8 mode): o_apb receives the AMX image (MXFP8, K = 576: 9 k64 steps) and o_scales its scale bytes
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s, void* o_scales = nullptr, bool bf16_once = false);
+                              int Tmax, bool x3, hipStream_t s, void* o_scales = nullptr, bool bf16_once = false, bool pages16 = false);
 // ---- misc ------------------------------------------------------------------------------------------------------
 void launch_argmax(const float* logits, int B, int V, int64_t ld, int32_t* tokens, hipStream_t s);
 

@@ -223,7 +223,9 @@ __device__ __forceinline__ void pax_split(const float (&v)[8], i32x4 (&p)[NP]) {
         p[0] = __builtin_bit_cast(i32x4, h);
     }
 }
-template <int NP>
+// P16 (NP = 1 only; fp8 mode with bf16 K/V pages written by the q/k/v epilogue): the loader wave copies -- a 16-byte load of a key's
+// 8 dims IS a K slot, and the V slots are eight 8-byte loads transposed with v_perm_b32; no conversion, half the page bytes.
+template <int NP, bool P16>
 __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attention_x3_kernel(const float* __restrict__ q, const float* __restrict__ k_cache,
                                                                    const float* __restrict__ v_cache, float* __restrict__ o,
                                                                    i32x4* __restrict__ o_apb, uint8_t* __restrict__ o_sc, int T, int Tmax) {
@@ -238,9 +240,56 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
         // ---------------- loader waves: wave 3 stages K, wave 4 stages V (PAX_LOADERS == 2; one wave does both otherwise):
         //                  8 float4 per lane per tile and operand, split, 12 sixteen-byte LDS stores ----------------
         const bool doK = PAX_LOADERS == 1 || wave == 3, doV = PAX_LOADERS == 1 || wave == 4;
-        f32x4 pk[8], pv[8];
         const int klo = lane & 7, oct = lane >> 3;               // K: keys klo + 8 i (i = 0..3), the 8 dims 8 oct .. 8 oct + 7
         const int q4 = lane & 15, t2 = (lane >> 4) & 1, hv = lane >> 5;     // V: dims 4 q4 .. + 3, key step t2, key half hv
+        if constexpr (P16) {
+            static_assert(NP == 1, "bf16 pages feed the bf16-once form only");
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            const uint16_t* kp16 = reinterpret_cast<const uint16_t*>(k_cache) + ((int64_t)b * 3 + g) * Tmax * 64;
+            const uint16_t* vp16 = reinterpret_cast<const uint16_t*>(v_cache) + ((int64_t)b * 3 + g) * Tmax * 64;
+            i32x4 rk[4];
+            u32x2_ rv[8];
+            auto fetch16 = [&](int kt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int t = kt * 32 + klo + 8 * i;
+                    t = t < T ? t : T - 1;
+                    rk[i] = *reinterpret_cast<const i32x4*>(kp16 + (int64_t)t * 64 + oct * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int t = kt * 32 + 16 * t2 + (j & 3) + 8 * (j >> 2) + 4 * hv;
+                    t = t < T ? t : T - 1;
+                    rv[j] = *reinterpret_cast<const u32x2_*>(vp16 + (int64_t)t * 64 + q4 * 4);
+                }
+            };
+            auto stage16 = [&](int st) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Kp[st][(oct >> 1) * 64 + klo + 8 * i + 32 * (oct & 1)] = rk[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {      // dim 4 q4 + e of keys j = 0..7: half (e & 1) of dword (e >> 1) of every load
+                    i32x4 pc;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const unsigned lo = rv[2 * jj][e >> 1], hi = rv[2 * jj + 1][e >> 1];
+                        pc[jj] = (int)((e & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u));
+                    }
+                    const int d = 4 * q4 + e;
+                    Vp[st][(t2 * 2 + (d >> 5)) * 64 + pax_sw((d & 31) + 32 * hv)] = pc;
+                }
+            };
+            fetch16(0);
+            stage16(0);
+            fetch16(qt >= 1 ? 1 : 0);
+            __syncthreads();
+            for (int kt = 0; kt <= qt; ++kt) {
+                stage16((kt + 1) & 1);
+                fetch16(kt + 2 <= qt ? kt + 2 : qt);
+                __syncthreads();
+            }
+            return;
+        }
+        f32x4 pk[8], pv[8];
         auto fetch = [&](int kt) {
             if (doK)
 #pragma unroll
@@ -442,11 +491,12 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
 
 // x3 = the bf16-split kernel (the engine's f32x3 mode), else exact fp32 MFMA
 void launch_prefill_attention(const float* q, const float* k_cache, const float* v_cache, float* o, void* o_apb, int B, int T,
-                              int Tmax, bool x3, hipStream_t s, void* o_scales, bool bf16_once) {
+                              int Tmax, bool x3, hipStream_t s, void* o_scales, bool bf16_once, bool pages16) {
     const int qtiles = (T + 31) / 32;
     uint8_t* sc = reinterpret_cast<uint8_t*>(o_scales);
-    if (x3 && bf16_once) hipLaunchKernelGGL(prefill_attention_x3_kernel<1>, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
-    else if (x3) hipLaunchKernelGGL(prefill_attention_x3_kernel<3>, dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    if (x3 && bf16_once && pages16) hipLaunchKernelGGL((prefill_attention_x3_kernel<1, true>), dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    else if (x3 && bf16_once) hipLaunchKernelGGL((prefill_attention_x3_kernel<1, false>), dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
+    else if (x3) hipLaunchKernelGGL((prefill_attention_x3_kernel<3, false>), dim3(qtiles, 3, B), dim3(PAX_THREADS), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
     else hipLaunchKernelGGL(prefill_attention_kernel, dim3(qtiles, 3, B), dim3(256), 0, s, q, k_cache, v_cache, o, reinterpret_cast<i32x4*>(o_apb), sc, T, Tmax);
 }
 
