@@ -243,8 +243,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                             o1[j] = __fadd_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(-x2[j], sn[j]));
                             o2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
                         }
-                        if (P >= g.q_heads && g.kv16) {      // fp8 mode: the key goes straight into the bf16 page (rounded once, RNE)
-                            __bf16* d16 = reinterpret_cast<__bf16*>(g.k_cache) + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
+                        if (g.kv16) {      // fp8 mode: the key goes straight into the bf16 page, the query into a bf16 row (rounded once, RNE)
+                            __bf16* d16 = P < g.q_heads ? reinterpret_cast<__bf16*>(g.q_out) + (int64_t)m * (g.q_heads * 64) + P * 64
+                                                        : reinterpret_cast<__bf16*>(g.k_cache) + (((int64_t)b * g.kv_heads + (P - g.q_heads)) * g.Tmax + t) * 64;
                             store4_bf16(d16 + i0, o1);
                             store4_bf16(d16 + 32 + i0, o2);
                         } else {

@@ -58,7 +58,7 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
-    int kv16 = 0;               // fp8 mode: k_cache / v_cache are bf16 pages (same element order, 2-byte elements): keys and values are stored rounded once
+    int kv16 = 0;               // fp8 mode: k_cache / v_cache are bf16 pages and q_out bf16 rows (same element order, 2-byte elements): stored rounded once
     // EPI_SWIGLU: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C.
     // EPI_LINEAR (round 4, norm-free chaining of the f32x3 LM prefill): when set, the stored value (accumulator + bias +
     // residual) is written to C AND pre-split to C3, and ssq_out[m * ssq_parts + P] receives its sum of squares over the

@@ -351,7 +351,17 @@ __global__ __launch_bounds__(PAX_THREADS, MELLOW_PAX_MINW) void prefill_attentio
     const int qc = qi < T ? qi : T - 1;
     // Q as B operand of the bf16 MFMA: step s, lane (query ql, half h) holds d = 16 s + 8 h + (0..7), pre-scaled by 1/8 (exact)
     i32x4 qp[4][NP];
-    {
+    if constexpr (P16) {      // q arrives as bf16 rows (rounded once by the q/k/v epilogue); x 1/8 is exact in bf16
+        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(q) + ((int64_t)b * T + qc) * 576 + hq * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const i32x4 r = *reinterpret_cast<const i32x4*>(qrow + 16 * s);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float((unsigned)r[j] << 16) * 0.125f; v[2 * j + 1] = __uint_as_float((unsigned)r[j] & 0xffff0000u) * 0.125f; }
+            pax_split<NP>(v, qp[s]);
+        }
+    } else {
         const float* qrow = q + ((int64_t)b * T + qc) * 576 + hq * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
