@@ -477,6 +477,19 @@ void launch_rmsnorm(const float* in, float* out, int M, int C, const float* w, f
 //     the 32-row output tile is 25 % padding);  48 + 64 = 112 MFMAs per tile instead of 3072 FMAs + 768 LDS broadcasts per lane.
 //   * out_apb (f32x3 mode, the proj GEMM runs on the x3q kernel): the output goes out pre-split in APB order instead of fp32 --
 //     a lane's quads are the epilogue quads of the GEMMs (common.h: apb_store_quads), head_dim 24 = three 8-column groups.
+//   * IN16 (fp8 mode, round 6): q / k / v arrive as bf16 rows (stored rounded once by the qkv GEMM's epilogue: half the bytes of the
+//     kernel's dominant stream) and are widened on load; the arithmetic below is unchanged.
+__device__ __forceinline__ void wa_ld4(const float* base, int64_t elem, bool in16, float (&o)[4]) {
+    if (in16) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ r = *reinterpret_cast<const u32x2_*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        o[0] = __uint_as_float(r[0] << 16); o[1] = __uint_as_float(r[0] & 0xffff0000u); o[2] = __uint_as_float(r[1] << 16); o[3] = __uint_as_float(r[1] & 0xffff0000u);
+    } else {
+        const float4 r = *reinterpret_cast<const float4*>(base + elem);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+    }
+}
+template <bool IN16>
 __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                     int C, int nH, const float* __restrict__ bias_exp,
                                                                     const float* __restrict__ mask, int nW,
@@ -493,20 +506,24 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float*
     float kf[2][12], qf[2][12];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const float* row = qkv + (win * 64 + t * 32 + ml) * (3 * C) + hd * 24 + 12 * h;
+        const int64_t row = (win * 64 + t * 32 + ml) * (3 * C) + hd * 24 + 12 * h;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            const float4 q4 = *reinterpret_cast<const float4*>(row + v * 4);
-            const float4 k4 = *reinterpret_cast<const float4*>(row + C + v * 4);
-            qf[t][4 * v] = q4.x * scale; qf[t][4 * v + 1] = q4.y * scale; qf[t][4 * v + 2] = q4.z * scale; qf[t][4 * v + 3] = q4.w * scale;
-            kf[t][4 * v] = k4.x; kf[t][4 * v + 1] = k4.y; kf[t][4 * v + 2] = k4.z; kf[t][4 * v + 3] = k4.w;
+            float q4[4], k4[4];
+            wa_ld4(qkv, row + v * 4, IN16, q4);
+            wa_ld4(qkv, row + C + v * 4, IN16, k4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qf[t][4 * v + j] = q4[j] * scale; kf[t][4 * v + j] = k4[j]; }
         }
     }
     {   // V tile of this wave -> LDS, row-major [key][24]
-        const float* vrow = qkv + (win * 64 + lane) * (3 * C) + 2 * C + hd * 24;
+        const int64_t vrow = (win * 64 + lane) * (3 * C) + 2 * C + hd * 24;
 #pragma unroll
-        for (int v = 0; v < 6; ++v)
-            *reinterpret_cast<float4*>(&Vs[wave][lane * 24 + v * 4]) = *reinterpret_cast<const float4*>(vrow + v * 4);
+        for (int v = 0; v < 6; ++v) {
+            float v4[4];
+            wa_ld4(qkv, vrow + v * 4, IN16, v4);
+            *reinterpret_cast<float4*>(&Vs[wave][lane * 24 + v * 4]) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        }
     }
     // S^T tiles [key tile kt][query tile qt]
     f32x16 S[2][2];
@@ -608,9 +625,14 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float*
     }
 }
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
-                             const float* mask, int nW, hipStream_t s, void* out_apb) {
+                             const float* mask, int nW, hipStream_t s, void* out_apb, bool qkv16) {
     const int64_t n_tiles = (int64_t)(M / 64) * nH;
-    hipLaunchKernelGGL(window_attention_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+    if (qkv16) {
+        hipLaunchKernelGGL(window_attention_mfma_kernel<true>, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
+                           bias_exp, mask, nW, n_tiles, reinterpret_cast<i32x4*>(out_apb));
+        return;
+    }
+    hipLaunchKernelGGL(window_attention_mfma_kernel<false>, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, qkv, out, C, nH,
                        bias_exp, mask, nW, n_tiles, reinterpret_cast<i32x4*>(out_apb));
 }
 

@@ -397,7 +397,7 @@ static const OptDesc kOptions[] = {
     {"fp8_prefill", "1", true, "fp8 mode: e4m3 GEMMs in encoder + LM prefill"},
     {"fp8_decode_act", "1", true, "fp8 mode: e4m3 activations in the decode GEMM kernels (fp8 matrix pipe)"},
     {"fp8_kv16", "1", true, "fp8 mode: bf16 shadow of the K/V pages for the decode step"},
-    {"fp8_attn_bf16", "1", true, "fp8 mode: prefill attention on operands rounded once to bf16 (0 = the fp32-accurate 3-way split of the f32x3 mode)"},
+    {"fp8_attn_bf16", "1", true, "fp8 mode: q / k / v stored once as bf16 (LM: bf16 K/V pages + bf16-once prefill attention; Swin: bf16 q/k/v rows into the exact window attention); 0 = fp32 q/k/v, the 3-way split attention"},
     {"decode_x3", "7", true, "f32x3: mask of decode GEMM launches on the bf16 pipe (1 lm_head, 2 gate/up, 4 fused down + q/k/v)"},
     {"decode_x3_min_rb", "2", true, "f32x3: fewest 32-row blocks at which the layer launches take their f32x3 forms"},
     {"x3_stft", "1", true, "f32x3: STFT / mel GEMMs on the split kernel (0 = exact fp32 kernel)"},

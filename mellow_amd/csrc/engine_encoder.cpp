@@ -184,7 +184,11 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
                     h3s = reinterpret_cast<char*>(e->enc_h3.p) + M1p * rup(4 * C, 64);
                 }
                 { ProfScope ps(e, PF_NORM, 0, 2.5 * M1 * C * 4); launch_layernorm_apb(x, e->enc_a3.p, M1, C, w.n1w, w.n1b, map, N, s, a3s); }
-                CHK(run_gemm_apb(e, lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b), e->enc_a3.p, s, a3s));
+                {
+                    GemmArgs g = lin(nullptr, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b);
+                    g.c16 = (amx && e->fp8_attn_bf16) ? 1 : 0;      // fp8 mode: q / k / v of the block as bf16 rows (the window attention widens them)
+                    CHK(run_gemm_apb(e, g, e->enc_a3.p, s, a3s));
+                }
             } else {
                 { ProfScope ps(e, PF_NORM, 0, 2.0 * M1 * C * 4); launch_layernorm(x, t, M1, C, w.n1w, w.n1b, map, N, s); }
                 CHK(run_gemm(e, lin(t, C, M1, w.qkv, e->QKV.p, 3 * C, w.qkv_b)));
@@ -193,7 +197,7 @@ int run_encoder(mellow_engine* e, const float* wav, int n, int64_t n_samples, in
             const bool apb_proj = apb && !amx && ((e->enc_apb_stages >> (4 + st)) & 1) && e->bf_w.count(w.proj.p);
             {
                 ProfScope ps(e, PF_WINDOW_ATTN, 4.0 * 64 * 64 * 24 * (double)(M1 / 64) * nH, 4.0 * M1 * C * 4);
-                launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s, apb_proj ? e->enc_a3.p : nullptr);
+                launch_window_attention(e->QKV.p, t, M1, C, nH, w.bias_exp, shifted ? w.mask : nullptr, nW, s, apb_proj ? e->enc_a3.p : nullptr, amx && e->fp8_attn_bf16);
             }
             {
                 GemmArgs g = lin(t, C, M1, w.proj, x, C, w.proj_b);

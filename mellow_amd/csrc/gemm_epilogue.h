@@ -16,7 +16,9 @@ __device__ __forceinline__ void store4_bf16(__bf16* dst, const float (&v)[4]) {
     *reinterpret_cast<bf16x4_*>(dst) = h;
 }
 
-template <int WN, int EPI>
+// C16: EPI_LINEAR stores C as bf16 (GemmArgs::c16).  AMX: a C3 output is an AMX image (GemmArgs::c3_fmt == 1: the fp8 kernel), else an APB
+// one (the f32x3 kernels).  Compile-time forms: each GEMM family carries only its own hand-over code and registers.
+template <int WN, int EPI, bool C16 = false, bool AMX = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int pm, int pn, int wm, int wn,
                                               int lane, int BM, int BN, const float* rs_rows = nullptr) {
     // rs_rows (optional): the row scales of this workgroup's BM rows, computed by the kernel BEFORE its main loop (LDS)
@@ -120,7 +122,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         const float4 r = pre_a[mi][ni][gq];
                         v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
                     }
-                    if (g.C) *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);   // (null: only the split copy is wanted)
+                    if (C16) { if (g.C) store4_bf16(reinterpret_cast<__bf16*>(g.C) + crow * g.ldc + col, v); }
+                    else if (g.C) *reinterpret_cast<float4*>(g.C + crow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);   // (null: only the split copy is wanted)
                     if (g.C3) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[ni][mi][4 * gq + j] = v[j];          // kept for the split store below
@@ -130,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             if (g.C3) {
                 // the stored row, pre-split for the next x3q GEMM, and its sum of squares over this wave's 64 columns
                 const int P = pn * WN + wn;
-                if (g.c3_fmt == 1) {           // fp8 mode: the consumer is gemm_mx8_kernel -- MXFP8 in AMX order (common.h), one scale per
+                if (AMX) {           // fp8 mode: the consumer is gemm_mx8_kernel -- MXFP8 in AMX order (common.h), one scale per
                     if (P * 64 < g.N) {        // 32 columns = per (ni) accumulator tile of the lane pair; N % 32 == 0 on this path
                         float ss = 0.f;
 #pragma unroll
@@ -145,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         if (h == 0 && g.ssq_out) g.ssq_out[(int64_t)m * g.ssq_parts + P] = ss;
                     }
                 } else
-                if (P * 64 < g.N) {            // wave-uniform (N is a multiple of 64 on this path)
+                if (!AMX && P * 64 < g.N) {            // wave-uniform (N is a multiple of 64 on this path)
                     float ss = 0.f;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
@@ -168,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             // pair epilogues: n-tile 2*wn holds the first half of the pair, 2*wn+1 the second
             const int P = pn * WN + wn;  // 64-column group index
             if constexpr (EPI == EPI_SWIGLU) {
-                if (g.C3 && g.c3_fmt == 1) {       // fp8 mode: silu(gate) * up as MXFP8 in AMX order; the wave's 32 columns are one block
+                if (AMX && g.C3) {       // fp8 mode: silu(gate) * up as MXFP8 in AMX order; the wave's 32 columns are one block
                     if (P * 32 >= g.N) continue;
                     float v[16];
 #pragma unroll
@@ -176,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     amx_store_block(reinterpret_cast<i32x4*>(g.C3), g.C3s, m, P, g.c3_kt64, (g.c3_kt64 + 3) >> 2, v, h);
                     continue;
                 }
-                if (g.C3) {       // the consumer is an x3q GEMM: write silu(gate) * up pre-split in APB order (N % 16 == 0)
+                if (!AMX && g.C3) {       // the consumer is an x3q GEMM: write silu(gate) * up pre-split in APB order (N % 16 == 0)
                     if (P * 32 >= g.N) continue;
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {

@@ -109,7 +109,7 @@ __device__ __forceinline__ void glds16_mx(const void* base, uint32_t voff, uint3
 // 128 x 128 tile, 4 waves (64 x 64 each: 4 accumulator tiles), one k64 step per stage (8 KiB per operand), ring of 3 stages filled
 // by LDS-DMA (waves 0, 1: the activation stage, waves 2, 3: the weight stage; four 1-KiB pieces per wave and step).  Per step and
 // wave: 8 ds_read_b128 feed 4 MFMAs of 64 cycles.  D[n][m] like every GEMM of the engine, so the epilogues are shared.
-template <int EPI>
+template <int EPI, bool C16>
 __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(const GemmMxDev p) {
     constexpr int BM = 128, BN = 128, WN = 2, NST = 3;
     constexpr int STAGE = 2 * 4 * 64;                                      // 16-byte slots per operand per stage
@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(const GemmMxDev p) {
             }
         }
     }
-    gemm_epilogue<WN, EPI>(g, acc, pm, pn, wm, wn, lane, BM, BN, g.rs_ssq ? rs_rows : nullptr);
+    gemm_epilogue<WN, EPI, C16, true>(g, acc, pm, pn, wm, wn, lane, BM, BN, g.rs_ssq ? rs_rows : nullptr);
 }
 
-template <int EPI>
+template <int EPI, bool C16 = false>
 static void launch8(const GemmArgs& a, hipStream_t s) {
     GemmMxDev d;
     d.a = a;
@@ -238,13 +238,13 @@ static void launch8(const GemmArgs& a, hipStream_t s) {
     d.ng = (d.gn % 8 == 0 && d.gn >= 16) ? 1 : 0;
     const int KT = (int)(a.lda8 >> 6), KQ = (KT + 3) / 4;
     const size_t lds = (size_t)2 * 3 * (2 * 4 * 64) * 16 + (size_t)KQ * 1024;          // 48 KiB of stages + the panel's scale words
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI>), 48 * 1024 + 24 * 1024);
-    hipLaunchKernelGGL((gemm_mx8_kernel<EPI>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&gemm_mx8_kernel<EPI, C16>), 48 * 1024 + 24 * 1024);
+    hipLaunchKernelGGL((gemm_mx8_kernel<EPI, C16>), dim3(d.gm * d.gn), dim3(256), lds, s, d);
 }
 // A8 / a_sc = AMX image + scale words of the activation (lda8 = K rounded up to 64), W8 / w_scale = WMX image + row scales
 void launch_gemm_fp8(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
-        case EPI_LINEAR: launch8<EPI_LINEAR>(a, s); break;
+        case EPI_LINEAR: if (a.c16) launch8<EPI_LINEAR, true>(a, s); else launch8<EPI_LINEAR>(a, s); break;
         case EPI_SWIGLU: launch8<EPI_SWIGLU>(a, s); break;
         case EPI_QKV_ROPE: launch8<EPI_QKV_ROPE>(a, s); break;
         default: break;   // EPI_POWER / EPI_LOGMEL stay on the fp32 kernel (front-end precision)

@@ -58,6 +58,7 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_pos][32]
     const float* rope_sin = nullptr;
     int T = 1, Tmax = 1, q_heads = 9, kv_heads = 3;
+    int c16 = 0;                // EPI_LINEAR: C is a bf16 matrix (ldc in elements): the output is stored rounded once (fp8 mode: q/k/v of the Swin blocks)
     int kv16 = 0;               // fp8 mode: k_cache / v_cache are bf16 pages and q_out bf16 rows (same element order, 2-byte elements): stored rounded once
     // EPI_SWIGLU: when set, the output is written pre-split in APB order (common.h) for an x3q consumer instead of to C.
     // EPI_LINEAR (round 4, norm-free chaining of the f32x3 LM prefill): when set, the stored value (accumulator + bias +
@@ -285,7 +286,7 @@ void launch_rmsnorm_apb(const float* in, void* out_apb, int M, int C, const floa
 // ---- Swin window attention -----------------------------------------------------------------------------
 // qkv [M][3C] rows in window order; out [M][C] window order.  bias_exp [nH][64][64]; mask [nW][64][64] or null
 void launch_window_attention(const float* qkv, float* out, int M, int C, int nH, const float* bias_exp,
-                             const float* mask, int nW, hipStream_t s, void* out_apb = nullptr);
+                             const float* mask, int nW, hipStream_t s, void* out_apb = nullptr, bool qkv16 = false);
 
 // ---- encoder tail -------------------------------------------------------------------------------------
 // y [n][64][768] (post final LN) -> latent [n][768] written into emb rows (n*emb_rows_stride) and im2col

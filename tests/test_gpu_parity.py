@@ -1370,7 +1370,9 @@ def test_fp8_mode_bf16_prefill_attention_stays_near_the_exact_one(synth_sd):
     for B in (1, 2, 33):
         a1, a2, ids = synth.make_batch(B)
         pre = ex.prefix(a1, a2, ids)
-        assert torch.equal(pre, eb.prefix(a1, a2, ids))                     # the encoder does not depend on the option
+        pb = eb.prefix(a1, a2, ids)          # (the option also stores the Swin blocks' q / k / v as bf16 rows: the encoder moves by bf16 rounding
+        rel_p = float((pb - pre).pow(2).mean().sqrt() / pre.pow(2).mean().sqrt())      #  amplified by the e4m3 GEMMs behind it, as far as the mode is from fp32)
+        assert torch.isfinite(pb).all() and rel_p < 0.08, (B, rel_p)
         lb, lx = eb.lm_prefill(pre, reserve=2), ex.lm_prefill(pre, reserve=2)
         rel_l = float((lb - lx).pow(2).mean().sqrt() / lx.pow(2).mean().sqrt())
         assert torch.isfinite(lb).all() and 1e-5 < rel_l < 0.15, (B, rel_l)
