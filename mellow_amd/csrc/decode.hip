@@ -365,7 +365,7 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __res
 }
 
 // ----------------------------------------------------------------------------------------------------
-// K2  attention (flash decoding).  grid (3 kv heads, rows, DEC_TS key splits), 8 waves.
+// K2  attention (flash decoding).  grid (3 kv heads, rows, key splits: DEC_TS at one row block, 1 from two on), 8 waves.
 //     r1 = RMS scale of x_new from the qkv kernel's per-chunk sums;  q,k,v = r1 * sum_kc pq slabs;  RoPE; KV append;
 //     per-wave online softmax over an interleaved set of 4-key groups; partial (m, l, o) per split.
 //     Split sp owns key groups [sp*gs, (sp+1)*gs) (the last split: everything from sp*gs on, plus the new key).
@@ -380,13 +380,35 @@ __global__ __launch_bounds__(QKV_THREADS) void dec_qkv_kernel(const float* __res
 #ifndef MELLOW_DA_MINW
 #define MELLOW_DA_MINW 4      // waves per SIMD the register allocation must allow: 4 = two 8-wave workgroups per CU (128 VGPRs), so that
 #endif                        // the 384 workgroups of a 64-row batch are resident together instead of in two rounds
-constexpr int DA_MINW = MELLOW_DA_WAVES == 8 ? MELLOW_DA_MINW : 1;
+constexpr int DA_MINW = MELLOW_DA_WAVES == 8 || MELLOW_DA_WAVES == 4 ? MELLOW_DA_MINW : 1;
 constexpr int DA_WAVES = MELLOW_DA_WAVES;
 constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chunk covers 2 * DA_WAVES * DA_G * 4 = 448 keys
 #ifndef MELLOW_DA_G1
 #define MELLOW_DA_G1 5      // 5 of 7: 48.55 ms of decode per 63 steps; 2 / 3 / 4 / 7 (= everything up front): 49.35 / 49.15 / 49.0 / 49.75 (same box)
 #endif
 constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key groups requested before the prologue
+// bf16 pages (KV16, the fp8 mode): the SCORES on the matrix pipe.  Ablations of the vector form at B = 128 (same box, decode per 63
+// steps): 75.5 ms; without the K/V loads 67.1; without the score / softmax / PV loop 60.3 -- 8 us of the 16.3 us launch are vector
+// issue (per 28 keys of a wave ~500 instructions: 84 of them the 16-lane DPP sums of 21 dot products, ~80 hazard s_nops, 63
+// redundant exps), not the stream.  Here a wave's chunk is ONE 32-key tile: lane (key kk = lane % 32, half hf = lane / 32)
+// loads the 64 contiguous bytes of its key's dims 32 hf .. 32 hf + 31 (four 16-byte loads = the B operands of four
+// v_mfma_f32_32x32x16_bf16, k order: step s <-> dims 32 hf + 8 s ..), the A operand holds q as EXACT bf16 triples in rows
+// 4 piece + head (rows are free: 32 of them, 9 used), so S = q . k is the fp32 dot product of the fp32 q with the bf16 key up to
+// summation order, one value per (key lane, head) -- no cross-lane sums, 3 exps per key.  The weights go through 4 KiB of LDS
+// (wave-private, in-order: no barrier) to the lanes of the unchanged P V accumulation (lane = key sub x dim quad).
+#ifndef MELLOW_DA16_MFMA
+#define MELLOW_DA16_MFMA 1
+#endif
+constexpr int DA_GM = 8;            // key groups per wave and chunk of the matrix form: 32 keys = one MFMA tile
+#ifndef MELLOW_DA16_KLDS
+#define MELLOW_DA16_KLDS 1          // the K tile of a wave = 32 CONSECUTIVE keys, loaded as 4 KiB of contiguous 16-byte pieces and turned into
+#endif                              // the operand order through a swizzled, wave-private LDS image (0: each lane loads its operand bytes itself)
+#ifndef MELLOW_DA16_KNT
+#define MELLOW_DA16_KNT 1
+#endif
+#ifndef MELLOW_DA16_MINW
+#define MELLOW_DA16_MINW MELLOW_DA_MINW
+#endif
 
 // KV16 (fp8 mode): the decode step reads and extends a bf16 SHADOW of the K/V pages (engine_lm.cpp: converted from the fp32
 // pages the prefill wrote, once per call): half the bytes of the step's largest stream.  The new key / value of the step itself
@@ -414,7 +436,7 @@ __device__ __forceinline__ void st_kv(float* page, int64_t elem, float v) {
 //      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
 //      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
 template <bool BLK, bool FUSED, bool ONE, bool KV16>
-__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
+__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA && DA_MINW > 1 ? MELLOW_DA16_MINW : DA_MINW)) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
                                                                   const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
                                                                   const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
                                                                   const DecArgs a) {
@@ -429,7 +451,15 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     __shared__ __attribute__((aligned(16))) float ored[DA_WAVES * 3 * 64];
     __shared__ float mred[DA_WAVES * 3], lred[DA_WAVES * 3];
     __shared__ float snew_s[3];
+    constexpr bool MF = KV16 && MELLOW_DA16_MFMA != 0;                   // scores on the matrix pipe (comment at DA_GM)
+    __shared__ __attribute__((aligned(16))) float pl[MF ? DA_WAVES * 32 * 4 : 4];     // softmax weights [wave][key of the tile][head | pad]
+    __shared__ __attribute__((aligned(16))) __bf16 qb[MF ? 10 * 64 : 8];               // q as bf16 triples [piece][head][dim] + a zero row
+    constexpr bool KL = MF && MELLOW_DA16_KLDS != 0;
+    __shared__ i32x4 kl[KL ? DA_WAVES * 32 * 8 : 1];                    // K tiles [wave][key][16-byte piece ^ (key % 8)]
+    // key of tile slot kk_ in the chunk that starts at group g0: KL = consecutive keys per wave, else the interleaved groups of the vector form
+    auto mf_group = [&](int g0, int u) { return KL ? g0 + u : g0 + u * DA_WAVES; };
 
+    constexpr int TS = ONE || KV16 ? DEC_TS : DEC_TS_MULTI;      // key splits: kernels.h dec_key_splits (ONE <=> a single row block)
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     int row = b;                  // the example whose KV pages this slot reads and extends (slot == example unless rows migrate)
     if (BLK) {
@@ -483,13 +513,40 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
     }
     const float c = a.rope_cur[i], sn = a.rope_cur[32 + i];
     const int gbeg = sp * gs_p;                                   // groups of 4 keys
-    const int gend_fixed = sp == DEC_TS - 1 ? 0x3fffffff : gbeg + gs_p;
+    const int gend_fixed = sp == TS - 1 ? 0x3fffffff : gbeg + gs_p;
     // The K/V stream of a workgroup (107 KB at 420 keys) is bound by what the memory side delivers per CU (~12 B/clk): a wave
     // that issues all 14 page loads up front sits in the issue queue for ~4 us, and the prologue's barriers wait for the
     // slowest wave.  So only the first DA_G1 key groups are requested before the prologue (enough bytes in flight to keep the
     // stream busy while it runs: slab sums, RoPE, two barriers); the rest is requested after it, and the score loop consumes
     // the groups in arrival order.
-    float4 k4[DA_G], v4[DA_G];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int kk = lane & 31, hf = lane >> 5;                     // matrix form: lane -> (key of the 32-key tile, half of its dims)
+    i32x4 kq[4];
+    u32x2 vq[DA_GM];
+    auto load_ktile = [&](int g0) {
+        if constexpr (KL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {          // instruction j: keys 8 j .. 8 j + 7 of the tile, 1 KiB of consecutive bytes
+                const int tc = min(g0 * 4 + 8 * j + (lane >> 3), Tmax - 1);
+                const i32x4* kp = reinterpret_cast<const i32x4*>(reinterpret_cast<const uint16_t*>(kpage) + (int64_t)tc * 64) + (lane & 7);
+                kq[j] = (MELLOW_DA_ABL & 1) ? i32x4{tc, 0x3c003c00, j, 0x3c003c00} : (MELLOW_DA16_KNT ? __builtin_nontemporal_load(kp) : *kp);
+            }
+        } else {
+            const int gi = g0 + (kk >> 2) * DA_WAVES;
+            const int tc = min(gi * 4 + (kk & 3), Tmax - 1);
+            const i32x4* kp = reinterpret_cast<const i32x4*>(reinterpret_cast<const uint16_t*>(kpage) + (int64_t)tc * 64 + hf * 32);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                kq[st] = (MELLOW_DA_ABL & 1) ? i32x4{tc, 0x3c003c00, st, 0x3c003c00} : (MELLOW_DA16_KNT ? __builtin_nontemporal_load(kp + st) : kp[st]);
+        }
+    };
+    auto load_vgroup = [&](int g0, int u) {
+        const int gi = mf_group(g0, u);
+        const int tc = min(gi * 4 + sub, Tmax - 1);
+        vq[u] = (MELLOW_DA_ABL & 1) ? u32x2{0x3c003c00u, (unsigned)tc}
+                                    : __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(vpage) + (int64_t)tc * 64 + quad * 4));
+    };
+    float4 k4[MF ? 1 : DA_G], v4[MF ? 1 : DA_G];
     auto load_group = [&](int u) {
         const int gi = gbeg + wave + u * DA_WAVES;
         const int tc = min(gi * 4 + sub, Tmax - 1);               // inside the page; validity is decided later
@@ -501,8 +558,15 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
             v4[u] = ld_kv<KV16>(vpage, (int64_t)tc * 64 + quad * 4);
         }
     };
+    const int g_first_mf = KL ? gbeg + wave * DA_GM : gbeg + wave;
+    if constexpr (MF) {
+        load_ktile(g_first_mf);
 #pragma unroll
-    for (int u = 0; u < DA_G1; ++u) load_group(u);
+        for (int u = 0; u < DA_GM / 2; ++u) load_vgroup(g_first_mf, u);
+    } else {
+#pragma unroll
+        for (int u = 0; u < DA_G1; ++u) load_group(u);
+    }
     MELLOW_HOIST(a.attF16); MELLOW_HOIST(a.att_ml); MELLOW_HOIST(a.RB); MELLOW_HOIST(a.eps);
     if (FUSED) MELLOW_HOIST(a.xnewR);
     __builtin_amdgcn_sched_barrier(0);
@@ -545,6 +609,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
         if (hsel < 3) {
             qs[hsel * 64 + i] = o1 * 0.125f;        // head_dim^-0.5 = 1/8 exactly
             qs[hsel * 64 + i + 32] = o2 * 0.125f;
+            if constexpr (MF) {                     // the same values as exact bf16 triples: the A operand of the score MFMAs
+                __bf16 p0, p1, p2;
+                split3(o1 * 0.125f, p0, p1, p2);
+                qb[(0 * 3 + hsel) * 64 + i] = p0; qb[(1 * 3 + hsel) * 64 + i] = p1; qb[(2 * 3 + hsel) * 64 + i] = p2;
+                split3(o2 * 0.125f, p0, p1, p2);
+                qb[(0 * 3 + hsel) * 64 + i + 32] = p0; qb[(1 * 3 + hsel) * 64 + i + 32] = p1; qb[(2 * 3 + hsel) * 64 + i + 32] = p2;
+            }
         } else {
             knew[i] = o1; knew[i + 32] = o2;
             if (sp == 0) { st_kv<KV16>(kpage, (int64_t)pos * 64 + i, o1); st_kv<KV16>(kpage, (int64_t)pos * 64 + i + 32, o2); }
@@ -553,11 +624,18 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
         const float x1 = xs[256 + tid - 128] * rs2;
         vnew[tid - 128] = x1;
         if (sp == 0) st_kv<KV16>(vpage, (int64_t)pos * 64 + (tid - 128), x1);
+    } else if (MF && tid < 256) {
+        qb[9 * 64 + tid - 192] = static_cast<__bf16>(0.f);
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MF) {
 #pragma unroll
-    for (int u = DA_G1; u < DA_G; ++u) load_group(u);
+        for (int u = DA_GM / 2; u < DA_GM; ++u) load_vgroup(g_first_mf, u);
+    } else {
+#pragma unroll
+        for (int u = DA_G1; u < DA_G; ++u) load_group(u);
+    }
     __builtin_amdgcn_sched_barrier(0);
     kstamp(1, 3, dbg);
 
@@ -566,8 +644,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : DA_MINW) void dec_attn_ker
         if (lane == 0) snew_s[wave] = sn_;
     }
     float4 q4[3];
+    // matrix form: row 4 piece + head of the A operand in the k order of the key lanes (step s: dims 32 hf + 8 s ..); rows without
+    // a (piece, head) read the zero row of qb.  Read from LDS per chunk: 16 registers less across the loop.
+    const int aq_off = ((kk >> 2) < 3 && (kk & 3) < 3 ? (kk >> 2) * 3 + (kk & 3) : 9) * 64 + hf * 32;
+    if constexpr (!MF) {
 #pragma unroll
-    for (int hh = 0; hh < 3; ++hh) q4[hh] = *reinterpret_cast<const float4*>(qs + hh * 64 + quad * 4);
+        for (int hh = 0; hh < 3; ++hh) q4[hh] = *reinterpret_cast<const float4*>(qs + hh * 64 + quad * 4);
+    }
     float m_run[3] = {-INFINITY, -INFINITY, -INFINITY};
     float l_run[3] = {0.f, 0.f, 0.f};      // per-lane partial (this lane's keys only)
     float4 acc[3];
@@ -629,7 +712,73 @@ _Pragma("unroll")                                                               
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-    if constexpr (ONE) {
+    // matrix form of a chunk (KV16): scores by four MFMAs, one softmax weight per (key lane, head), P V as above
+    auto chunk_mf = [&](int g0) {
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        if constexpr (KL) {
+            i32x4* klw = kl + wave * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 8 * j + (lane >> 3);
+                klw[r * 8 + ((lane & 7) ^ (r & 7))] = kq[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int st = 0; st < 4; ++st) kq[st] = klw[kk * 8 + ((4 * hf + st) ^ (kk & 7))];
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const i32x4 aq = *reinterpret_cast<const i32x4*>(qb + aq_off + 8 * st);
+            MELLOW_BF16(aq, kq[st], sacc);
+        }
+        // output lane (key kk, half hf'): rows 8 (r / 4) + 4 hf' + r % 4 -> piece 0 in r = head (hf' = 0), piece 1 in r = head (hf' = 1),
+        // piece 2 in r = 4 + head (hf' = 0); rows 12 .. 14 (r = 4 + head, hf' = 1) are zero rows of A
+        const int gi = mf_group(g0, kk >> 2), t = gi * 4 + (kk & 3);
+        const bool ok = gi < gend && t < pos;
+        float pw[3], alpha[3];
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+            float sv = half_sum(sacc[hh] + sacc[4 + hh]);              // both halves of the wave hold the key's score
+            sv = ok ? sv : -INFINITY;
+            float cm = row16_max(sv);
+            cm = fmaxf(cm, swz_xor16(cm));                            // max over the 32 keys of the tile (at least one is valid)
+            const float m_new = fmaxf(m_run[hh], cm);
+            alpha[hh] = fast_exp(m_run[hh] - m_new);
+            m_run[hh] = m_new;
+            pw[hh] = fast_exp(sv - m_new);
+            l_run[hh] = l_run[hh] * alpha[hh] + pw[hh];               // per key lane; summed over the tile's lanes at the end
+        }
+        float4* plw = reinterpret_cast<float4*>(pl) + wave * 32;
+        if (hf == 0) plw[kk] = make_float4(pw[0], pw[1], pw[2], 0.f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-private hand-over: LDS operations of a wave complete in order
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) acc[hh] = make_float4(acc[hh].x * alpha[hh], acc[hh].y * alpha[hh], acc[hh].z * alpha[hh], acc[hh].w * alpha[hh]);
+#pragma unroll
+        for (int u = 0; u < DA_GM; ++u) {
+            const float4 pp = plw[4 * u + sub];                        // the three heads' weights of key (u, sub): one address per 16 lanes
+            const float4 v = make_float4(__uint_as_float(vq[u][0] << 16), __uint_as_float(vq[u][0] & 0xffff0000u),
+                                         __uint_as_float(vq[u][1] << 16), __uint_as_float(vq[u][1] & 0xffff0000u));
+            acc[0].x += pp.x * v.x; acc[0].y += pp.x * v.y; acc[0].z += pp.x * v.z; acc[0].w += pp.x * v.w;
+            acc[1].x += pp.y * v.x; acc[1].y += pp.y * v.y; acc[1].z += pp.y * v.z; acc[1].w += pp.y * v.w;
+            acc[2].x += pp.z * v.x; acc[2].y += pp.z * v.y; acc[2].z += pp.z * v.z; acc[2].w += pp.z * v.w;
+        }
+        asm volatile("" ::: "memory");                                 // the next chunk's weights are written after these reads
+    };
+    if constexpr (MF) {
+#pragma clang loop unroll(disable)
+        for (int g0 = g_first_mf; g0 < g_stop; g0 += DA_WAVES * DA_GM) {
+            if (g0 != g_first_mf) {          // later chunks (contexts beyond 256 keys per split): reload, then the same body
+                load_ktile(g0);
+#pragma unroll
+                for (int u = 0; u < DA_GM; ++u) load_vgroup(g0, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            chunk_mf(g0);
+        }
+    } else if constexpr (ONE) {
         for (int g0 = g_first; g0 < g_stop; g0 += DA_WAVES * DA_G) {
             if (g0 != g_first) MELLOW_DA_RELOAD(g0)        // later chunks (only for contexts beyond 448 keys per split)
             MELLOW_DA_CHUNK(g0)
@@ -649,8 +798,13 @@ _Pragma("unroll")                                                               
 #pragma unroll
     for (int hh = 0; hh < 3; ++hh) {
         float l = l_run[hh];                 // identical across the 16 quads of a sub; sum over the 4 subs
-        l += swz_xor16(l);
-        l = half_sum(l);
+        if constexpr (MF) {                  // matrix form: one partial per key lane, the two halves of the wave hold the same 32
+            l = row16_sum(l);
+            l += swz_xor16(l);
+        } else {
+            l += swz_xor16(l);
+            l = half_sum(l);
+        }
         acc[hh].x += swz_xor16(acc[hh].x); acc[hh].y += swz_xor16(acc[hh].y);
         acc[hh].z += swz_xor16(acc[hh].z); acc[hh].w += swz_xor16(acc[hh].w);
         acc[hh].x = half_sum(acc[hh].x); acc[hh].y = half_sum(acc[hh].y);
@@ -660,7 +814,7 @@ _Pragma("unroll")                                                               
     }
     __syncthreads();
     kstamp(1, 5, dbg);
-    static_assert(DA_WAVES == 8 || DA_WAVES == 16, "the merge below reduces over 8-lane groups");
+    static_assert(DA_WAVES == 8 || DA_WAVES == 16 || DA_WAVES == 4, "the merge below reduces over 8-lane groups (8 waves) or serially");
     if (DA_WAVES == 8 && tid < 384) {
         // thread -> (pair = (head hh, dim quad dq), wave w): the 8 waves' partials of a pair sit in 8 adjacent lanes and are
         // combined with three DPP steps (xor 1, xor 2, mirror of the 8-lane half-row) instead of a serial loop in 48 threads
@@ -671,7 +825,7 @@ _Pragma("unroll")                                                               
         M = fmaxf(M, dpp_mov<0xB1>(M));
         M = fmaxf(M, dpp_mov<0x4E>(M));
         M = fmaxf(M, dpp_mov<0x141>(M));
-        if (sp == DEC_TS - 1) M = fmaxf(M, snew);          // the last split also owns the new key
+        if (sp == TS - 1) M = fmaxf(M, snew);          // the last split also owns the new key
         const float f = M > -INFINITY ? fast_exp(mw - M) : 0.f;      // waves without keys: m = -inf -> factor 0; an empty split: all 0
         const float4 ow = *reinterpret_cast<const float4*>(ored + (w * 3 + hh) * 64 + dq * 4);
         float L = lred[w * 3 + hh] * f;
@@ -680,7 +834,7 @@ _Pragma("unroll")                                                               
         MELLOW_R8(L); MELLOW_R8(O.x); MELLOW_R8(O.y); MELLOW_R8(O.z); MELLOW_R8(O.w);
 #undef MELLOW_R8
         if (w == 0) {
-            if (sp == DEC_TS - 1 && M > -INFINITY) {
+            if (sp == TS - 1 && M > -INFINITY) {
                 const float pn = fast_exp(snew - M);
                 const float4 vn = *reinterpret_cast<const float4*>(vnew + dq * 4);
                 L += pn;
@@ -692,20 +846,20 @@ _Pragma("unroll")                                                               
             const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
             st_out(reinterpret_cast<float4*>(a.attF16) + o4, O);
             if (dq == 0)      // (m, l) of this split: [head][row][split] pairs, so that the o_proj reads both splits of a row with one 16-byte load
-                *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
+                *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * TS + sp) * 2) = make_float2(M, L);
         }
     }
     if (DA_WAVES != 8 && tid < 48) {
         // thread -> (head hh, dim quad dq): merged float4 of the waves (+ the new key on the last split), serial form
         const int hh = tid >> 4, dq = tid & 15;
         const float snew = snew_s[hh];
-        float M = sp == DEC_TS - 1 ? snew : -INFINITY;   // the last split also owns the new key
+        float M = sp == TS - 1 ? snew : -INFINITY;   // the last split also owns the new key
 #pragma unroll
         for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, mred[w * 3 + hh]);
         float L = 0.f;
         float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
         if (M > -INFINITY) {                 // an empty split (short context) publishes m = -inf, l = 0, o = 0
-            if (sp == DEC_TS - 1) {
+            if (sp == TS - 1) {
                 const float pn = fast_exp(snew - M);
                 const float4 vn = *reinterpret_cast<const float4*>(vnew + dq * 4);
                 L = pn;
@@ -724,7 +878,7 @@ _Pragma("unroll")                                                               
         const int64_t o4 = ((((int64_t)sp * a.RB + rb) * 36 + (k >> 4)) * 2 + (m >> 4)) * 64 + (m & 15) + 16 * ((k >> 2) & 3);
         reinterpret_cast<float4*>(a.attF16)[o4] = O;
         if (dq == 0)
-            *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * DEC_TS + sp) * 2) = make_float2(M, L);
+            *reinterpret_cast<float2*>(a.att_ml + (((int64_t)head * a.rows + b) * TS + sp) * 2) = make_float2(M, L);
     }
     kstamp(1, 6, dbg);
     kspan(a.dbg_seq, 1);
@@ -748,7 +902,7 @@ constexpr int OP_WAVES = MELLOW_OPROJ_WAVES;
 // bytes one CU has to ingest)
 // Chosen per launch: 8 rows for a single row block (B <= 32: 52.8 -> 52.2 ms of decode per 63 steps), 16 rows otherwise (at
 // B = 64 the 288 eight-row workgroups no longer fit the 256 CUs: 76.3 -> 78.5 ms).  MELLOW_OPROJ_ROWS forces one form.
-template <bool BLK, int W8, int OP_ROWS>
+template <bool BLK, int W8, int OP_ROWS, int TS>
 __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* __restrict__ Wp16, const float* __restrict__ attF16_p,
                                                                   const float* __restrict__ att_ml_p, const float* __restrict__ xnewR_p,
                                                                   int RB_p, int rows_p, const DecArgs a,
@@ -771,9 +925,9 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
     float4 xres = make_float4(0.f, 0.f, 0.f, 0.f);
     if (erow_ok) xres = *reinterpret_cast<const float4*>(xnewR_p + erow * 576 + nt * 16 + enq * 4);
 
-    float4 w[TPW], os[TPW][DEC_TS];
+    float4 w[TPW], os[TPW][TS];
     uint32_t w8[TPW];
-    float ms[TPW][DEC_TS], ls[TPW][DEC_TS];
+    float ms[TPW][TS], ls[TPW][TS];
     const int64_t row = (int64_t)rb * 32 + mh * 16 + ml;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -787,18 +941,21 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         }
         const int h = tc >> 2;                                        // tile = 16 k of head h
 #pragma unroll
-        for (int s = 0; s < DEC_TS; ++s) {
+        for (int s = 0; s < TS; ++s) {
             ms[i][s] = 0.f; ls[i][s] = 1.f; os[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);     // rows of another workgroup: x = 0
             if (lrow) os[i][s] = reinterpret_cast<const float4*>(attF16_p)[((((int64_t)s * RB_p + rb) * 36 + tc) * 2 + mh) * 64 + lane];
         }
         if (lrow) {
-            const float* mlp = att_ml_p + ((int64_t)h * rows_p + row) * DEC_TS * 2;
-            if constexpr (DEC_TS == 2) {                     // (m, l) of both splits of the row: one 16-byte load
+            const float* mlp = att_ml_p + ((int64_t)h * rows_p + row) * TS * 2;
+            if constexpr (TS == 2) {                     // (m, l) of both splits of the row: one 16-byte load
                 const float4 v = *reinterpret_cast<const float4*>(mlp);
                 ms[i][0] = v.x; ls[i][0] = v.y; ms[i][1] = v.z; ls[i][1] = v.w;
+            } else if constexpr (TS == 1) {
+                const float2 v = *reinterpret_cast<const float2*>(mlp);
+                ms[i][0] = v.x; ls[i][0] = v.y;
             } else {
 #pragma unroll
-                for (int s = 0; s < DEC_TS; ++s) { ms[i][s] = mlp[2 * s]; ls[i][s] = mlp[2 * s + 1]; }
+                for (int s = 0; s < TS; ++s) { ms[i][s] = mlp[2 * s]; ls[i][s] = mlp[2 * s + 1]; }
             }
         }
     }
@@ -811,11 +968,11 @@ __global__ __launch_bounds__(OP_WAVES * 64) void dec_oproj_kernel(const float* _
         // merge the key splits: x = sum_s f_s o_s / sum_s f_s l_s, f_s = exp(m_s - max m)
         float M = ms[i][0];
 #pragma unroll
-        for (int s = 1; s < DEC_TS; ++s) M = fmaxf(M, ms[i][s]);
+        for (int s = 1; s < TS; ++s) M = fmaxf(M, ms[i][s]);
         float L = 0.f;
         float4 O = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int s = 0; s < DEC_TS; ++s) {
+        for (int s = 0; s < TS; ++s) {
             const float f = fast_exp(ms[i][s] - M);
             L += ls[i][s] * f;
             O.x += os[i][s].x * f; O.y += os[i][s].y * f; O.z += os[i][s].z * f; O.w += os[i][s].w * f;
@@ -2004,7 +2161,12 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 #undef MELLOW_QKV
 }
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
-    const dim3 grid(3, a.rows, DEC_TS), block(DA_WAVES * 64);
+    const dim3 grid(3, a.rows, a.ts), block(DA_WAVES * 64);
+    const bool one = a.RB == 1 && !a.blk_live;
+    if (a.ts != (one || a.kv16 ? DEC_TS : DEC_TS_MULTI)) {      // the kernels derive their split count from ONE (dec_key_splits: RB == 1 <=> DEC_TS splits)
+        fprintf(stderr, "mellow: decode attention launched with %d key splits at RB = %d\n", a.ts, a.RB);
+        abort();
+    }
 #define MELLOW_DA(BLKV, FUSEDV, ONEV)                                                                                    \
     do {                                                                                                                 \
         if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
@@ -2013,7 +2175,7 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
                                 (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);                      \
     } while (0)
     // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)
-    if (a.RB == 1 && !a.blk_live) {
+    if (one) {
         if (fused) MELLOW_DA(false, true, true); else MELLOW_DA(false, false, true);
     } else if (a.blk_live && fused) MELLOW_DA(true, true, false);
     else if (a.blk_live) MELLOW_DA(true, false, false);
@@ -2121,19 +2283,22 @@ __global__ __launch_bounds__(256) void compose_f64_kernel(const float* __restric
 void launch_compose_f64(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
     hipLaunchKernelGGL(compose_f64_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, A, B, C, M, N, K);
 }
-int dec_attn_chunk_groups() { return DA_WAVES * DA_G; }
+int dec_attn_chunk_groups(bool kv16) { return DA_WAVES * (kv16 && MELLOW_DA16_MFMA ? DA_GM : DA_G); }
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
 #ifdef MELLOW_OPROJ_ROWS
     const int rows = MELLOW_OPROJ_ROWS;
 #else
     const int rows = a.RB == 1 ? 8 : 16;
 #endif
+#define MELLOW_OPROJ_L(BLKV, W8V, ROWSV, TSV, PARTSV)                                                                      \
+    hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, ROWSV, TSV>), dim3(36, PARTSV * a.RB), dim3(OP_WAVES * 64), 0, s, Wp16,    \
+                       (const float*)a.attF16, (const float*)a.att_ml, (const float*)a.xnewR, a.RB, a.rows, a, wscale)
 #define MELLOW_OPROJ(BLKV, W8V)                                                                                             \
     do {                                                                                                                    \
-        if (rows == 8) hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 8>), dim3(36, 4 * a.RB), dim3(OP_WAVES * 64), 0, s, Wp16,  \
-                                          (const float*)a.attF16, (const float*)a.att_ml, (const float*)a.xnewR, a.RB, a.rows, a, wscale); \
-        else hipLaunchKernelGGL((dec_oproj_kernel<BLKV, W8V, 16>), dim3(36, 2 * a.RB), dim3(OP_WAVES * 64), 0, s, Wp16,          \
-                                (const float*)a.attF16, (const float*)a.att_ml, (const float*)a.xnewR, a.RB, a.rows, a, wscale);           \
+        if (rows == 8 && a.ts == 1) MELLOW_OPROJ_L(BLKV, W8V, 8, 1, 4);                                                     \
+        else if (rows == 8) MELLOW_OPROJ_L(BLKV, W8V, 8, DEC_TS, 4);                                                        \
+        else if (a.ts == 1) MELLOW_OPROJ_L(BLKV, W8V, 16, 1, 2);                                                            \
+        else MELLOW_OPROJ_L(BLKV, W8V, 16, DEC_TS, 2);                                                                      \
     } while (0)
     const int mode = w8_mode(a, wscale);
     if (a.blk_live && mode == 2) MELLOW_OPROJ(true, 2);
@@ -2143,6 +2308,7 @@ void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const 
     else if (mode == 1) MELLOW_OPROJ(false, 1);
     else MELLOW_OPROJ(false, 0);
 #undef MELLOW_OPROJ
+#undef MELLOW_OPROJ_L
 }
 void launch_dec_gateup(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale) {
     MELLOW_LAUNCH_BLK_W8(dec_gateup16_kernel, dim3(192, a.RB), dim3(GU_WAVES * 64), Wp16, a.xmidF16, a.ssq, a);

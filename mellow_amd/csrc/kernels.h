@@ -123,7 +123,17 @@ constexpr int DEC_KC_DOWN = MELLOW_DEC_KC_DOWN;   // down: 192 k-tiles = 8 chunk
 #ifndef MELLOW_DEC_TS
 #define MELLOW_DEC_TS 2
 #endif
-constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention, merged by the o_proj prologue
+constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention at ONE row block (merged by the o_proj prologue); the buffers are sized for it
+// Batches of two or more row blocks run ONE split (DecArgs::ts): the launch already has >= 192 workgroups, a second split only
+// repeats the prologue and doubles the partials the o_proj ingests (same box, decode per 63 steps at B = 64: 63.7 -> 60.5 ms;
+// tokens unchanged).  Not in the fp8 mode (bf16 pages): there a row's tokens must not depend on the batch around it (an e4m3
+// rounding downstream turns the 1e-7 of another summation order into another token: test_fp8_mode_end_to_end), so the split
+// count is the same for every batch size.
+#ifndef MELLOW_DEC_TS_MULTI
+#define MELLOW_DEC_TS_MULTI 1
+#endif
+constexpr int DEC_TS_MULTI = MELLOW_DEC_TS_MULTI;
+inline int dec_key_splits(int RB, bool kv16) { return RB <= 1 || kv16 ? DEC_TS : DEC_TS_MULTI; }
 // dec_qkv2_kernel (down projection of layer l + q/k/v of layer l+1 in one launch): k-chunks of the h part, waves, derived counts
 #ifndef MELLOW_Q2_HC
 #define MELLOW_Q2_HC 4
@@ -149,6 +159,7 @@ struct DecArgs {
     int first = 0;                 // set on the first qkv launch of a step: stage rope_cur (and, with inc_pos, advance d_pos)
     int inc_pos = 0;
     int gs = 1;                    // attention: 4-key groups per key split (fixed per launch; last split takes the rest)
+    int ts = DEC_TS;               // key splits of this batch's attention launches: dec_key_splits(RB)
     float* rope_cur = nullptr;     // [64] cos | sin of the current position
     float* ssq1 = nullptr;         // [rows][DEC_KC_QKV] per-k-chunk sums of squares of x_new (qkv kernel -> attention)
     const float* rope_cos = nullptr;
@@ -159,8 +170,8 @@ struct DecArgs {
     float* dslabF = nullptr;       // down split-K slabs [DEC_KC_DOWN] x F32-layout
     int64_t slabF_stride4 = 0;     // float4 elements between F-layout slabs
     float* pq = nullptr;           // qkv split-K slabs [DEC_KC_QKV][rows][960]
-    float* attF16 = nullptr;       // attention partial outputs [DEC_TS][RB][36][2][64][4] (F16-layout)
-    float* att_ml = nullptr;       // (running max, sum of weights) of every key split: [9 heads][rows][DEC_TS][2]
+    float* attF16 = nullptr;       // attention partial outputs [ts][RB][36][2][64][4] (F16-layout)
+    float* att_ml = nullptr;       // (running max, sum of weights) of every key split: [9 heads][rows][ts][2]
     float* ssq = nullptr;          // [rows][40] per-o_proj-tile sums of squares of x_mid
     float* xmidF16 = nullptr;      // x_mid in F16-layout (gate/up operand)
     float* guF = nullptr;          // h = SwiGLU(gate, up) [RB][192][64][4] (F32-layout B operand of the down projection)
@@ -209,7 +220,7 @@ void launch_dec_qkv2_w8(const DecArgs& a, const float* Wx8, const float* sc_x, c
                         const float* Wd8, const float* sc_d, hipStream_t s);
 // C[M][N] = A[M][K] . B[K][N], fp64 accumulate, rounded once to fp32 (row-major device buffers)
 void launch_compose_f64(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
-int dec_attn_chunk_groups();   // 4-key groups one attention workgroup covers per pass
+int dec_attn_chunk_groups(bool kv16);   // 4-key groups one attention workgroup covers per pass
 void launch_dec_oproj(const DecArgs& a, const float* Wp16, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_gateup(const DecArgs& a, const float* Wp16_folded_pairs, hipStream_t s, const float* wscale = nullptr);
 void launch_dec_down(const DecArgs& a, const float* Wp, int K8p, hipStream_t s, const float* wscale = nullptr);
