@@ -388,26 +388,35 @@ constexpr int DA_G = MELLOW_DA_G;   // 4-key groups in flight per wave: one chun
 #endif
 constexpr int DA_G1 = MELLOW_DA_G1 < DA_G ? MELLOW_DA_G1 : DA_G;    // key groups requested before the prologue
 // bf16 pages (KV16, the fp8 mode): the SCORES on the matrix pipe.  Ablations of the vector form at B = 128 (same box, decode per 63
-// steps): 75.5 ms; without the K/V loads 67.1; without the score / softmax / PV loop 60.3 -- 8 us of the 16.3 us launch are vector
-// issue (per 28 keys of a wave ~500 instructions: 84 of them the 16-lane DPP sums of 21 dot products, ~80 hazard s_nops, 63
-// redundant exps), not the stream.  Here a wave's chunk is ONE 32-key tile: lane (key kk = lane % 32, half hf = lane / 32)
+// steps): 75.5 ms; without the K/V loads 67.1; without the score / softmax / PV loop 60.3 (per 28 keys of a wave ~500 vector
+// instructions: 84 of them the 16-lane DPP sums of 21 dot products, ~80 hazard s_nops, 63
+// redundant exps).  Here a wave's chunk is ONE 32-key tile (~200 vector instructions): lane (key kk = lane % 32, half hf = lane / 32)
 // loads the 64 contiguous bytes of its key's dims 32 hf .. 32 hf + 31 (four 16-byte loads = the B operands of four
 // v_mfma_f32_32x32x16_bf16, k order: step s <-> dims 32 hf + 8 s ..), the A operand holds q as EXACT bf16 triples in rows
 // 4 piece + head (rows are free: 32 of them, 9 used), so S = q . k is the fp32 dot product of the fp32 q with the bf16 key up to
 // summation order, one value per (key lane, head) -- no cross-lane sums, 3 exps per key.  The weights go through 4 KiB of LDS
 // (wave-private, in-order: no barrier) to the lanes of the unchanged P V accumulation (lane = key sub x dim quad).
+// Same box, fp8 mode, decode per 63 steps: B = 128 75.9 -> 72.4 ms, B = 32 43.9 -> 41.7; with the loads compiled out the two forms
+// cost the same (66.5 / 67.1): the loop is a dependent chain (scores -> max -> exp -> weights -> P V) more than an issue stream, and
+// what the matrix form wins is the chain's length and the registers (116 instead of 218 at one row block).
 #ifndef MELLOW_DA16_MFMA
 #define MELLOW_DA16_MFMA 1
 #endif
 constexpr int DA_GM = 8;            // key groups per wave and chunk of the matrix form: 32 keys = one MFMA tile
-#ifndef MELLOW_DA16_KLDS
-#define MELLOW_DA16_KLDS 1          // the K tile of a wave = 32 CONSECUTIVE keys, loaded as 4 KiB of contiguous 16-byte pieces and turned into
-#endif                              // the operand order through a swizzled, wave-private LDS image (0: each lane loads its operand bytes itself)
 #ifndef MELLOW_DA16_KNT
-#define MELLOW_DA16_KNT 1
-#endif
+#define MELLOW_DA16_KNT 0           // K tile loads plain: a lane's four 16-byte pieces share a 64-byte segment that four instructions touch, and a
+#endif                              // non-temporal line does not stay for the next one (same box, fp8 B = 128: 78.9 ms with nt, 72.5 without)
+// Measured and dropped: the tile as 32 consecutive keys loaded in 1 KiB runs and turned into the operand order through a swizzled
+// LDS image (72.8 against 72.5 ms: the LDS round trip costs what the coalescing gains).
+// Physical waves (template parameter NW): the eight chunk streams of a workgroup ("virtual waves": own weights region, own
+// partial in the merge) can run on 8 waves or, two after the other, on 4 -- the same arithmetic in the same order, so the
+// results are bit-identical and four 256-thread workgroups share a CU (the 768 workgroups of B = 128 resident together instead
+// of in 1.5 rounds).  Measured +-0 (fp8 B = 128, same box: 72.4 ms on 8 waves, 72.4-73.5 on 4): MELLOW_DA16_NW stays 8.
 #ifndef MELLOW_DA16_MINW
 #define MELLOW_DA16_MINW MELLOW_DA_MINW
+#endif
+#ifndef MELLOW_DA16_NW
+#define MELLOW_DA16_NW 8            // physical waves of the matrix form from two row blocks on (4 = two virtual waves per wave)
 #endif
 
 // KV16 (fp8 mode): the decode step reads and extends a bf16 SHADOW of the K/V pages (engine_lm.cpp: converted from the fp32
@@ -435,8 +444,8 @@ __device__ __forceinline__ void st_kv(float* page, int64_t elem, float v) {
 // ONE: the launch has a single 32-row block (192 workgroups: one per CU, registers are free) -> the chunk loop in its plain form
 //      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
 //      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
-template <bool BLK, bool FUSED, bool ONE, bool KV16>
-__global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA && DA_MINW > 1 ? MELLOW_DA16_MINW : DA_MINW)) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
+template <bool BLK, bool FUSED, bool ONE, bool KV16, int NW>
+__global__ __launch_bounds__(NW * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA && DA_MINW > 1 ? MELLOW_DA16_MINW : DA_MINW)) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
                                                                   const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
                                                                   const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
                                                                   const DecArgs a) {
@@ -454,10 +463,10 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA 
     constexpr bool MF = KV16 && MELLOW_DA16_MFMA != 0;                   // scores on the matrix pipe (comment at DA_GM)
     __shared__ __attribute__((aligned(16))) float pl[MF ? DA_WAVES * 32 * 4 : 4];     // softmax weights [wave][key of the tile][head | pad]
     __shared__ __attribute__((aligned(16))) __bf16 qb[MF ? 10 * 64 : 8];               // q as bf16 triples [piece][head][dim] + a zero row
-    constexpr bool KL = MF && MELLOW_DA16_KLDS != 0;
-    __shared__ i32x4 kl[KL ? DA_WAVES * 32 * 8 : 1];                    // K tiles [wave][key][16-byte piece ^ (key % 8)]
-    // key of tile slot kk_ in the chunk that starts at group g0: KL = consecutive keys per wave, else the interleaved groups of the vector form
-    auto mf_group = [&](int g0, int u) { return KL ? g0 + u : g0 + u * DA_WAVES; };
+    constexpr int VPW = DA_WAVES / NW;                                   // virtual waves per physical wave (matrix form only)
+    static_assert(DA_WAVES % NW == 0 && (MF || NW == DA_WAVES), "the vector form runs one chunk stream per wave");
+    // key group of slot u in the chunk that starts at group g0: the interleaved groups of the vector form
+    auto mf_group = [&](int g0, int u) { return g0 + u * DA_WAVES; };
 
     constexpr int TS = ONE || KV16 ? DEC_TS : DEC_TS_MULTI;      // key splits: kernels.h dec_key_splits (ONE <=> a single row block)
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
@@ -524,21 +533,12 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA 
     i32x4 kq[4];
     u32x2 vq[DA_GM];
     auto load_ktile = [&](int g0) {
-        if constexpr (KL) {
+        const int gi = g0 + (kk >> 2) * DA_WAVES;
+        const int tc = min(gi * 4 + (kk & 3), Tmax - 1);
+        const i32x4* kp = reinterpret_cast<const i32x4*>(reinterpret_cast<const uint16_t*>(kpage) + (int64_t)tc * 64 + hf * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {          // instruction j: keys 8 j .. 8 j + 7 of the tile, 1 KiB of consecutive bytes
-                const int tc = min(g0 * 4 + 8 * j + (lane >> 3), Tmax - 1);
-                const i32x4* kp = reinterpret_cast<const i32x4*>(reinterpret_cast<const uint16_t*>(kpage) + (int64_t)tc * 64) + (lane & 7);
-                kq[j] = (MELLOW_DA_ABL & 1) ? i32x4{tc, 0x3c003c00, j, 0x3c003c00} : (MELLOW_DA16_KNT ? __builtin_nontemporal_load(kp) : *kp);
-            }
-        } else {
-            const int gi = g0 + (kk >> 2) * DA_WAVES;
-            const int tc = min(gi * 4 + (kk & 3), Tmax - 1);
-            const i32x4* kp = reinterpret_cast<const i32x4*>(reinterpret_cast<const uint16_t*>(kpage) + (int64_t)tc * 64 + hf * 32);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-                kq[st] = (MELLOW_DA_ABL & 1) ? i32x4{tc, 0x3c003c00, st, 0x3c003c00} : (MELLOW_DA16_KNT ? __builtin_nontemporal_load(kp + st) : kp[st]);
-        }
+        for (int st = 0; st < 4; ++st)
+            kq[st] = (MELLOW_DA_ABL & 1) ? i32x4{tc, 0x3c003c00, st, 0x3c003c00} : (MELLOW_DA16_KNT ? __builtin_nontemporal_load(kp + st) : kp[st]);
     };
     auto load_vgroup = [&](int g0, int u) {
         const int gi = mf_group(g0, u);
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA 
             v4[u] = ld_kv<KV16>(vpage, (int64_t)tc * 64 + quad * 4);
         }
     };
-    const int g_first_mf = KL ? gbeg + wave * DA_GM : gbeg + wave;
+    const int g_first_mf = gbeg + wave;                           // virtual wave wave + NW j starts at group g_first_mf + NW j
     if constexpr (MF) {
         load_ktile(g_first_mf);
 #pragma unroll
@@ -713,22 +713,10 @@ _Pragma("unroll")                                                               
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
     // matrix form of a chunk (KV16): scores by four MFMAs, one softmax weight per (key lane, head), P V as above
-    auto chunk_mf = [&](int g0) {
+    auto chunk_mf = [&](int vw, int g0) {
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        if constexpr (KL) {
-            i32x4* klw = kl + wave * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 8 * j + (lane >> 3);
-                klw[r * 8 + ((lane & 7) ^ (r & 7))] = kq[j];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int st = 0; st < 4; ++st) kq[st] = klw[kk * 8 + ((4 * hf + st) ^ (kk & 7))];
-            asm volatile("" ::: "memory");
-        }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const i32x4 aq = *reinterpret_cast<const i32x4*>(qb + aq_off + 8 * st);
@@ -751,7 +739,7 @@ _Pragma("unroll")                                                               
             pw[hh] = fast_exp(sv - m_new);
             l_run[hh] = l_run[hh] * alpha[hh] + pw[hh];               // per key lane; summed over the tile's lanes at the end
         }
-        float4* plw = reinterpret_cast<float4*>(pl) + wave * 32;
+        float4* plw = reinterpret_cast<float4*>(pl) + vw * 32;
         if (hf == 0) plw[kk] = make_float4(pw[0], pw[1], pw[2], 0.f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-private hand-over: LDS operations of a wave complete in order
 #pragma unroll
@@ -767,16 +755,48 @@ _Pragma("unroll")                                                               
         }
         asm volatile("" ::: "memory");                                 // the next chunk's weights are written after these reads
     };
-    if constexpr (MF) {
-#pragma clang loop unroll(disable)
-        for (int g0 = g_first_mf; g0 < g_stop; g0 += DA_WAVES * DA_GM) {
-            if (g0 != g_first_mf) {          // later chunks (contexts beyond 256 keys per split): reload, then the same body
-                load_ktile(g0);
+    // reduce the 4 key-subs of the wave; publish (m, l, o) of the (virtual) wave vw
+    auto publish = [&](int vw) {
 #pragma unroll
-                for (int u = 0; u < DA_GM; ++u) load_vgroup(g0, u);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int hh = 0; hh < 3; ++hh) {
+            float l = l_run[hh];                 // identical across the 16 quads of a sub; sum over the 4 subs
+            if constexpr (MF) {                  // matrix form: one partial per key lane, the two halves of the wave hold the same 32
+                l = row16_sum(l);
+                l += swz_xor16(l);
+            } else {
+                l += swz_xor16(l);
+                l = half_sum(l);
             }
-            chunk_mf(g0);
+            float4 o = acc[hh];
+            o.x += swz_xor16(o.x); o.y += swz_xor16(o.y);
+            o.z += swz_xor16(o.z); o.w += swz_xor16(o.w);
+            o.x = half_sum(o.x); o.y = half_sum(o.y);
+            o.z = half_sum(o.z); o.w = half_sum(o.w);
+            if (sub == 0) *reinterpret_cast<float4*>(ored + (vw * 3 + hh) * 64 + quad * 4) = o;
+            if (lane == 0) { mred[vw * 3 + hh] = m_run[hh]; lred[vw * 3 + hh] = l; }
+        }
+    };
+    if constexpr (MF) {
+        // virtual wave wave + NW j of this physical wave, one after the other on the same registers: its chunks
+        // gbeg + vw + c * (DA_WAVES * DA_GM) below g_stop, then its partial; the first chunk of j = 0 was requested around the prologue
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < VPW; ++j) {
+            const int vw = wave + NW * j;
+            if (j != 0) {
+#pragma unroll
+                for (int hh = 0; hh < 3; ++hh) { m_run[hh] = -INFINITY; l_run[hh] = 0.f; acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            }
+#pragma clang loop unroll(disable)
+            for (int g0 = gbeg + vw; g0 < g_stop; g0 += DA_WAVES * DA_GM) {
+                if (g0 != g_first_mf) {          // every chunk but the first: load, then the same body
+                    load_ktile(g0);
+#pragma unroll
+                    for (int u = 0; u < DA_GM; ++u) load_vgroup(g0, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                chunk_mf(vw, g0);
+            }
+            publish(vw);
         }
     } else if constexpr (ONE) {
         for (int g0 = g_first; g0 < g_stop; g0 += DA_WAVES * DA_G) {
@@ -793,32 +813,17 @@ _Pragma("unroll")                                                               
     }
 #undef MELLOW_DA_CHUNK
 #undef MELLOW_DA_RELOAD
+    if constexpr (!MF) publish(wave);
     kstamp(1, 4, dbg && l_run[0] == l_run[0]);
-    // reduce the 4 key-subs of the wave; publish (m, l, o) of the wave
-#pragma unroll
-    for (int hh = 0; hh < 3; ++hh) {
-        float l = l_run[hh];                 // identical across the 16 quads of a sub; sum over the 4 subs
-        if constexpr (MF) {                  // matrix form: one partial per key lane, the two halves of the wave hold the same 32
-            l = row16_sum(l);
-            l += swz_xor16(l);
-        } else {
-            l += swz_xor16(l);
-            l = half_sum(l);
-        }
-        acc[hh].x += swz_xor16(acc[hh].x); acc[hh].y += swz_xor16(acc[hh].y);
-        acc[hh].z += swz_xor16(acc[hh].z); acc[hh].w += swz_xor16(acc[hh].w);
-        acc[hh].x = half_sum(acc[hh].x); acc[hh].y = half_sum(acc[hh].y);
-        acc[hh].z = half_sum(acc[hh].z); acc[hh].w = half_sum(acc[hh].w);
-        if (sub == 0) *reinterpret_cast<float4*>(ored + (wave * 3 + hh) * 64 + quad * 4) = acc[hh];
-        if (lane == 0) { mred[wave * 3 + hh] = m_run[hh]; lred[wave * 3 + hh] = l; }
-    }
     __syncthreads();
     kstamp(1, 5, dbg);
     static_assert(DA_WAVES == 8 || DA_WAVES == 16 || DA_WAVES == 4, "the merge below reduces over 8-lane groups (8 waves) or serially");
-    if (DA_WAVES == 8 && tid < 384) {
-        // thread -> (pair = (head hh, dim quad dq), wave w): the 8 waves' partials of a pair sit in 8 adjacent lanes and are
+    if (DA_WAVES == 8)
+#pragma unroll
+    for (int it = tid; it < 384; it += NW * 64) {      // (whole 8-lane groups: 384 and NW * 64 are multiples of 8)
+        // item -> (pair = (head hh, dim quad dq), wave w): the 8 waves' partials of a pair sit in 8 adjacent lanes and are
         // combined with three DPP steps (xor 1, xor 2, mirror of the 8-lane half-row) instead of a serial loop in 48 threads
-        const int w = tid & 7, pair = tid >> 3, hh = pair >> 4, dq = pair & 15;
+        const int w = it & 7, pair = it >> 3, hh = pair >> 4, dq = pair & 15;
         const float mw = mred[w * 3 + hh];
         const float snew = snew_s[hh];
         float M = mw;
@@ -2167,11 +2172,13 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
         fprintf(stderr, "mellow: decode attention launched with %d key splits at RB = %d\n", a.ts, a.RB);
         abort();
     }
+    // bf16 pages, matrix form: MELLOW_DA16_NW physical waves from two row blocks on -- kernel comment at DA_GM
 #define MELLOW_DA(BLKV, FUSEDV, ONEV)                                                                                    \
     do {                                                                                                                 \
-        if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+        constexpr int NW16 = MELLOW_DA16_MFMA && DA_WAVES == 8 && !(ONEV) ? MELLOW_DA16_NW : DA_WAVES;                     \
+        if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true, NW16>), grid, dim3(NW16 * 64), 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
                                        (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);               \
-        else hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+        else hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false, DA_WAVES>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
                                 (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);                      \
     } while (0)
     // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)
