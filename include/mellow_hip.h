@@ -39,8 +39,11 @@ extern "C" {
  *  1: the DEFAULT numeric mode of mellow_engine_create is MELLOW_PRECISION_F32X3 (round 4).  A caller that never calls
  *     mellow_engine_set_precision gets fp32-accurate GEMMs whose LAST BITS depend on how many examples share the call
  *     (split-K for small launches; from round 5 the decode step of a batch of more than 32 rows runs other kernels than one of
- *     up to 32 rows): greedy tokens are asserted equal across those forms on the reference's fixtures, logits agree to 1e-3;
- *     a caller that needs bit-identical, batch-size-independent GEMMs selects MELLOW_PRECISION_F32.
+ *     up to 32 rows; from round 6 its attention merges one key split instead of two from two row blocks on): greedy tokens are
+ *     asserted equal across those forms on the reference's fixtures, logits agree to 1e-3.  A caller that needs
+ *     batch-size-independent GEMMs selects MELLOW_PRECISION_F32: encoder and prefill are then bit-identical whatever the batch;
+ *     the decode step still picks wave counts per launch by the number of 32-row blocks (another fp32 summation order: <= 5e-4
+ *     on the logits, same arg-max: tests/test_gpu_parity.py test_exact_fp32_mode_across_batch_sizes).
  *  2: mellow_prefill_parts (round 5).
  *  3: mellow_engine_set_option / mellow_engine_describe (round 6): the library no longer reads ANY environment variable; every
  *     switch it has is a named option, and the resolved configuration can be printed.  mellow_debug_gemm_f32 modes 6 / 9 are gone

@@ -444,7 +444,7 @@ __device__ __forceinline__ void st_kv(float* page, int64_t elem, float v) {
 // ONE: the launch has a single 32-row block (192 workgroups: one per CU, registers are free) -> the chunk loop in its plain form
 //      (221 VGPRs, 0.7 ms of decode per 63 steps faster at B = 32); otherwise the first chunk is peeled by hand so that the kernel
 //      fits 128 VGPRs and two workgroups share a CU (B = 64: 384 workgroups resident together, 73.7 -> 71.2 ms)
-template <bool BLK, bool FUSED, bool ONE, bool KV16, int NW>
+template <bool BLK, bool FUSED, bool ONE, bool KV16, int NW, int TS>
 __global__ __launch_bounds__(NW * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA && DA_MINW > 1 ? MELLOW_DA16_MINW : DA_MINW)) void dec_attn_kernel(float* __restrict__ k_cache, float* __restrict__ v_cache,
                                                                   const int32_t* __restrict__ d_pos_p, const float* __restrict__ pq_p,
                                                                   const float* __restrict__ xmidF_p, int Tmax_p, int gs_p, int rows_p,
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, ONE ? 2 : (KV16 && MELLOW_DA16_MFMA && DA_
     // key group of slot u in the chunk that starts at group g0: the interleaved groups of the vector form
     auto mf_group = [&](int g0, int u) { return g0 + u * DA_WAVES; };
 
-    constexpr int TS = ONE || KV16 ? DEC_TS : DEC_TS_MULTI;      // key splits: kernels.h dec_key_splits (ONE <=> a single row block)
+    static_assert(TS == DEC_TS || !(ONE || KV16), "one row block and the bf16 pages always run DEC_TS key splits (kernels.h dec_key_splits)");
     const int g = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     int row = b;                  // the example whose KV pages this slot reads and extends (slot == example unless rows migrate)
     if (BLK) {
@@ -2183,7 +2183,7 @@ void launch_dec_qkv(const DecArgs& a, const float* Wp, int K8p, int kcd, hipStre
 void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fused, hipStream_t s) {
     const dim3 grid(3, a.rows, a.ts), block(DA_WAVES * 64);
     const bool one = a.RB == 1 && !a.blk_live;
-    if (a.ts != (one || a.kv16 ? DEC_TS : DEC_TS_MULTI)) {      // the kernels derive their split count from ONE (dec_key_splits: RB == 1 <=> DEC_TS splits)
+    if (a.ts != DEC_TS && (one || a.kv16 || a.ts != DEC_TS_MULTI)) {      // kernels.h dec_key_splits
         fprintf(stderr, "mellow: decode attention launched with %d key splits at RB = %d\n", a.ts, a.RB);
         abort();
     }
@@ -2191,9 +2191,12 @@ void launch_dec_attn(const DecArgs& a, float* k_cache, float* v_cache, bool fuse
 #define MELLOW_DA(BLKV, FUSEDV, ONEV)                                                                                    \
     do {                                                                                                                 \
         constexpr int NW16 = MELLOW_DA16_MFMA && DA_WAVES == 8 && !(ONEV) ? MELLOW_DA16_NW : DA_WAVES;                     \
-        if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true, NW16>), grid, dim3(NW16 * 64), 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+        constexpr int TSM = (ONEV) ? DEC_TS : DEC_TS_MULTI;        /* (ONE never meets another split count) */            \
+        if (a.kv16) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, true, NW16, DEC_TS>), grid, dim3(NW16 * 64), 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
                                        (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);               \
-        else hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false, DA_WAVES>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+        else if (a.ts == DEC_TS) hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false, DA_WAVES, DEC_TS>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
+                                                    (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);  \
+        else hipLaunchKernelGGL((dec_attn_kernel<BLKV, FUSEDV, ONEV, false, DA_WAVES, TSM>), grid, block, 0, s, k_cache, v_cache, (const int32_t*)a.d_pos, \
                                 (const float*)a.pq, (const float*)a.xmidF, a.Tmax, a.gs, a.rows, a);                      \
     } while (0)
     // (the per-block early exit exists only with more than one row block, so <BLK, ONE> never meet)

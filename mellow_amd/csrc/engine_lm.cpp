@@ -89,7 +89,7 @@ int ensure_lm(mellow_engine* e, int B, int T, int Tmax, int ctx_end) {
             // key split of the decode attention: balanced at the END of the reserved context, rounded down to whole
             // passes of a workgroup when that costs at most 4 groups of imbalance
             const int ng_end = (ctx_end - 1 + 3) / 4, chunk = dec_attn_chunk_groups(e->kv16);
-            a.ts = dec_key_splits((int)RB, e->kv16);
+            a.ts = dec_key_splits((int)RB, e->kv16 || e->mode != MELLOW_PRECISION_F32X3);
             int gs = (ng_end + a.ts - 1) / a.ts;
             if (gs > chunk && gs % chunk <= 4) gs -= gs % chunk;
             gs = gs < 1 ? 1 : gs;

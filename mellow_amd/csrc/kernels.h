@@ -124,16 +124,17 @@ constexpr int DEC_KC_DOWN = MELLOW_DEC_KC_DOWN;   // down: 192 k-tiles = 8 chunk
 #define MELLOW_DEC_TS 2
 #endif
 constexpr int DEC_TS = MELLOW_DEC_TS;   // key splits of the decode attention at ONE row block (merged by the o_proj prologue); the buffers are sized for it
-// Batches of two or more row blocks run ONE split (DecArgs::ts): the launch already has >= 192 workgroups, a second split only
-// repeats the prologue and doubles the partials the o_proj ingests (same box, decode per 63 steps at B = 64: 63.7 -> 60.5 ms;
-// tokens unchanged).  Not in the fp8 mode (bf16 pages): there a row's tokens must not depend on the batch around it (an e4m3
-// rounding downstream turns the 1e-7 of another summation order into another token: test_fp8_mode_end_to_end), so the split
-// count is the same for every batch size.
+// Batches of two or more row blocks run ONE split in the default mode (DecArgs::ts): the launch already has >= 192 workgroups, a
+// second split only repeats the prologue and doubles the partials the o_proj ingests (same box, decode per 63 steps at B = 64:
+// 63.9 -> 60.6 ms; tokens unchanged).  Only in the f32x3 mode, whose last bits depend on the batch size anyway (mellow_hip.h, ABI
+// minor 1): the exact-fp32 mode keeps its promise of batch-size-independent arithmetic, and in the fp8 mode a row's TOKENS must not
+// depend on the batch around it (an e4m3 rounding downstream turns the 1e-7 of another summation order into another token:
+// test_fp8_mode_end_to_end) -- there the split count is DEC_TS for every batch size.
 #ifndef MELLOW_DEC_TS_MULTI
 #define MELLOW_DEC_TS_MULTI 1
 #endif
 constexpr int DEC_TS_MULTI = MELLOW_DEC_TS_MULTI;
-inline int dec_key_splits(int RB, bool kv16) { return RB <= 1 || kv16 ? DEC_TS : DEC_TS_MULTI; }
+inline int dec_key_splits(int RB, bool fixed) { return RB <= 1 || fixed ? DEC_TS : DEC_TS_MULTI; }
 // dec_qkv2_kernel (down projection of layer l + q/k/v of layer l+1 in one launch): k-chunks of the h part, waves, derived counts
 #ifndef MELLOW_Q2_HC
 #define MELLOW_Q2_HC 4

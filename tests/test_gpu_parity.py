@@ -335,6 +335,31 @@ def test_multi_row_block_decode_logits_match_the_one_block_path(engine, engine_f
             assert torch.equal(got.argmax(-1), small_steps[i].argmax(-1))
 
 
+def test_exact_fp32_mode_across_batch_sizes(engine_f32):
+    """What MELLOW_PRECISION_F32 promises about the batch size (`include/mellow_hip.h`, ABI minor 1), pinned: the LM of a 72-row
+    batch (two row blocks + a quarter) against the same rows run alone through the one-block kernels.  Encoder-side and prefill
+    arithmetic does not depend on the batch: the PREFILL logits are equal bit for bit.  The decode step picks wave counts per
+    launch by the number of row blocks (4-way against 12-way LDS reductions in the fused down + q/k/v launch, 8- against 16-row
+    o_proj workgroups) -- another fp32 summation order, measured 9e-5 on the logits: asserted <= 5e-4 with equal arg-max, for
+    3 teacher-forced steps; the attention keeps its two key splits at every batch size in this mode (kernels.h `dec_key_splits`)."""
+    B, pick = 72, [0, 33, 70, 71]
+    a1, a2, ids = synth.make_batch(B)
+    pre_big = engine_f32.prefix(a1, a2, ids)
+    sub = torch.from_numpy(np.asarray(pick)).to(pre_big.device)
+    pre_small = pre_big[sub].clone()
+    small = [engine_f32.lm_prefill(pre_small, reserve=8).clone()]
+    for i in range(3):
+        small.append(engine_f32.lm_decode_step(small[-1].argmax(-1)).clone())
+    l_big = engine_f32.lm_prefill(pre_big, reserve=8)
+    assert torch.equal(l_big[sub], small[0]), f"prefill: max |d| {float((l_big[sub] - small[0]).abs().max()):.3e}"
+    for i in range(1, 4):
+        full = l_big.argmax(-1)
+        full[sub] = small[i - 1].argmax(-1)
+        l_big = engine_f32.lm_decode_step(full)
+        _close(l_big[sub], small[i], rel=0, atol=5e-4, name=f"f32 mode, decode step {i}: rows of the 72-batch vs the same rows alone")
+        assert torch.equal(l_big[sub].argmax(-1), small[i].argmax(-1))
+
+
 @pytest.fixture(scope="module")
 def batch1024():
     return synth.make_batch(1024)
