@@ -1328,6 +1328,41 @@ def test_fp8_decode_on_the_fp8_pipe_stays_near_the_fp32_activation_form(synth_sd
         e.close()
 
 
+def test_fp8_decode_attention_chunks_and_key_splits_agree(synth_sd):
+    """bf16-page decode attention (fp8 mode: scores on the matrix pipe, decode.hip at `DA_GM`): a wave walks its keys in chunks of
+    one 32-key tile and rescales its running (m, l, o) between chunks, and the key range is cut into two splits at a boundary that
+    follows the RESERVED context.  Every benchmarked configuration keeps a split inside one chunk; here the same 389-key prefix is
+    decoded with 8 and with 400 reserved positions -- the second puts keys 0..395 into split 0 as TWO chunks per wave (rescale
+    path, partly masked second tile) and leaves split 1 with the appended keys only.  Same arithmetic in another summation order;
+    in this mode an e4m3 activation rounding downstream turns the 1e-7 into a flipped code here and there, so the logits of the
+    teacher-forced steps agree to 1.5e-2 .. 2.6e-2 relative rms (measured; the vector form of the kernel, -DMELLOW_DA16_MFMA=0,
+    shows the same 1.5e-2 .. 2.6e-2 on the same box: the figure is the mode's, not the kernel's) -- asserted < 6e-2, with both runs
+    at the mode's own distance (0.05 .. 0.18) from the fp32-accurate engine on the structured checkpoint.  A wrong rescale or mask
+    would put O(1) errors into every row."""
+    from mellow_amd.engine import Engine
+    sds = synth.make_state_dict(0, structured=True)
+    e8, e32 = Engine(device=0, precision="fp8"), Engine(device=0, precision="f32x3")
+    e8.load_state_dict(sds); e32.load_state_dict(sds)
+    a1, a2, ids = synth.make_batch(8)
+    pre = e32.prefix(a1, a2, ids)
+    ref = [e32.lm_prefill(pre, reserve=8).clone()]
+    for i in range(3):
+        ref.append(e32.lm_decode_step(ref[-1].argmax(-1)).clone())
+    runs = []
+    for reserve in (8, 400):
+        out = [e8.lm_prefill(pre, reserve=reserve).clone()]
+        for i in range(3):
+            out.append(e8.lm_decode_step(ref[i].argmax(-1)).clone())     # teacher-forced with the fp32-accurate tokens
+        runs.append(out)
+    rr = lambda x, y: float((x - y).pow(2).mean().sqrt() / y.pow(2).mean().sqrt())
+    for i in range(4):              # (step 0 = the prompt's last position: it runs through the decode kernels too)
+        d = rr(runs[1][i], runs[0][i])
+        assert torch.isfinite(runs[1][i]).all() and d < 6e-2, (i, d)
+        assert rr(runs[0][i], ref[i]) < 0.35 and rr(runs[1][i], ref[i]) < 0.35, (i, rr(runs[0][i], ref[i]), rr(runs[1][i], ref[i]))
+        print(f"step {i}: reserve 400 vs 8 rel rms {d:.2e}; vs f32x3 {rr(runs[0][i], ref[i]):.3f} / {rr(runs[1][i], ref[i]):.3f}")
+    e8.close(); e32.close()
+
+
 def test_fp8_mode_end_to_end(synth_sd, engine_f32, golden_dir):
     """precision="fp8": e4m3 GEMMs in the Swin linears and LM prefill, e4m3 WEIGHTS in the five decode GEMM kernels and the
     lm_head (fp32 activations there); front-end, attentions and norms fp32.  Not bit-exact by design; the test pins (a)
